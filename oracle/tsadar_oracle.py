@@ -1,0 +1,611 @@
+"""CPU oracle (NumPy float64) for the Thomson-scattering form-factor hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``tsadar_amd/`` may import this module; only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do, and
+only as the checker / the CPU baseline.
+
+This is a restatement, written from reading the sources, of the algorithm in the reference
+(ergodicio/tsadar @ 2025-08-24).  The reference is Python on JAX and cannot be imported in the
+build container (jax, equinox, interpax are not installed -- ordinary ModuleNotFoundError, no
+permission denial), so parity is pinned through the reference's own fixtures:
+
+  * ``tests/test_forward/ThryE-1d.npy`` (golden vector of ``tests/test_forward/test_1d.py``),
+    committed as ``tests/golden/ref_ThryE-1d.npy``      -> ``tests/test_oracle_golden.py``
+  * the Bohm-Gross known-answer test ``tests/test_form_factor/test_epw.py:33-74``
+  * the ion-acoustic known-answer test ``tests/test_form_factor/test_iaw.py:40-71``
+
+Third-party arithmetic that the reference calls and that is restated here (versions are
+unpinned in the reference's requirements.txt): ``interpax.interp1d(method="cubic")`` (C1 cubic
+Hermite with mean-of-secants node slopes), ``jnp.interp``, ``jnp.gradient``, ``jnp.convolve``.
+
+Every function cites the reference file:line it follows (paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import os
+from functools import lru_cache
+
+import numpy as np
+from scipy.special import gamma as _gamma, gammaincc as _gammaincc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DATA = os.path.join(_HERE, "..", "tsadar_amd", "data")
+
+# ---------------------------------------------------------------------------------------------
+# constants  (tsadar/core/physics/form_factor.py:123-125, 207-209)
+# ---------------------------------------------------------------------------------------------
+C = 2.99792458e10  # cm/s
+ME = 510.9896 / C**2  # keV / c^2
+MP = ME * 1836.1
+RE = 2.8179e-13  # cm
+ESQ = ME * C**2 * RE
+C0 = np.sqrt(4 * np.pi * ESQ / ME)
+
+XI_MINMAX = 8.2
+XI_H = 0.01
+XI_H1 = 1024
+
+
+# ---------------------------------------------------------------------------------------------
+# small numerical primitives
+# ---------------------------------------------------------------------------------------------
+def interp_linear(x, xp, fp, left=None, right=None):
+    """``jnp.interp`` (call sites form_factor.py:247-248, 270): piecewise linear, the segment is
+    ``clip(searchsorted(xp, x, 'right'), 1, n-1)``; outside the table ``left``/``right`` (which may
+    be arrays shaped like ``x``) or the end values when they are None."""
+    x = np.asarray(x, dtype=np.float64)
+    i = np.clip(np.searchsorted(xp, x, side="right"), 1, len(xp) - 1)
+    dx = xp[i] - xp[i - 1]
+    df = fp[i] - fp[i - 1]
+    f = fp[i - 1] + ((x - xp[i - 1]) / dx) * df
+    lo = fp[0] if left is None else left
+    hi = fp[-1] if right is None else right
+    f = np.where(x < xp[0], lo, f)
+    f = np.where(x > xp[-1], hi, f)
+    return f
+
+
+def hermite_slopes(x, f):
+    """Node slopes of interpax's ``method="cubic"`` (interpax ``_approx_df``): the mean of the two
+    adjacent secants, one-sided at both ends."""
+    d = np.diff(f) / np.diff(x)
+    return np.concatenate([d[:1], 0.5 * (d[:-1] + d[1:]), d[-1:]])
+
+
+def interp_hermite(xq, x, f, lo, hi):
+    """``interpax.interp1d(xq, x, f, method="cubic", extrap=[lo, hi])`` (call sites
+    form_factor.py:256, 263): C1 cubic Hermite; constant ``lo``/``hi`` outside ``[x[0], x[-1]]``."""
+    xq = np.asarray(xq, dtype=np.float64)
+    fx = hermite_slopes(x, f)
+    i = np.clip(np.searchsorted(x, xq, side="right"), 1, len(x) - 1)
+    dx = x[i] - x[i - 1]
+    t = (xq - x[i - 1]) / dx
+    f0, f1 = f[i - 1], f[i]
+    m0, m1 = fx[i - 1] * dx, fx[i] * dx
+    c2 = -3 * f0 + 3 * f1 - 2 * m0 - m1
+    c3 = 2 * f0 - 2 * f1 + m0 + m1
+    fq = f0 + t * (m0 + t * (c2 + t * c3))
+    fq = np.where(xq < x[0], lo, fq)
+    fq = np.where(xq > x[-1], hi, fq)
+    return fq
+
+
+def gradient_uniform(f, h):
+    """``jnp.gradient(f, h)`` (form_factor.py:264): central differences, one-sided at the ends."""
+    g = np.empty_like(f)
+    g[1:-1] = (f[2:] - f[:-2]) / (2 * h)
+    g[0] = (f[1] - f[0]) / h
+    g[-1] = (f[-1] - f[-2]) / h
+    return g
+
+
+# ---------------------------------------------------------------------------------------------
+# static grids and tables  (form_factor.py:20-45, 128-139)
+# ---------------------------------------------------------------------------------------------
+@lru_cache(maxsize=None)
+def xi_grids():
+    xi1 = np.linspace(-XI_MINMAX - np.sqrt(2.0) / XI_H1, XI_MINMAX + np.sqrt(2.0) / XI_H1, XI_H1)
+    xi2 = np.arange(-XI_MINMAX, XI_MINMAX, XI_H)
+    return xi1, xi2
+
+
+@lru_cache(maxsize=None)
+def zprime_tables():
+    """Z' tables sampled on xi2 (form_factor.py:33-44, 139): linear interpolation of the two text
+    tables (|xi| <= 10); xi2 never leaves that range so the asymptotic branches are empty."""
+    _, xi2 = xi_grids()
+    rd = np.loadtxt(os.path.join(_DATA, "rdWT.txt"))
+    im = np.loadtxt(os.path.join(_DATA, "idWT.txt"))
+    zr = np.interp(xi2, rd[:, 0], rd[:, 1])
+    zi = np.interp(xi2, im[:, 0], im[:, 1])
+    return zr, zi
+
+
+# ---------------------------------------------------------------------------------------------
+# ratintn  (tsadar/core/physics/ratintn.py:4-52)
+# ---------------------------------------------------------------------------------------------
+def ratcen(f, g):
+    """ratintn.py:26-52.  ``f``: [N], ``g``: [..., N]; returns [..., N-2] (last interval dropped)."""
+    fdif = f[1:-1] - f[0:-2]
+    gdif = g[..., 1:-1] - g[..., 0:-2]
+    fav = 0.5 * (f[1:-1] + f[0:-2])
+    gav = 0.5 * (g[..., 1:-1] + g[..., 0:-2])
+    tmp = fav * gdif - gav * fdif
+    rf = fav / gav + tmp * gdif / (12.0 * gav**3)
+    # real part of the complex logarithm = log of the modulus
+    rfn = fdif / gdif + tmp * np.log(np.abs((gav + 0.5 * gdif) / (gav - 0.5 * gdif))) / gdif**2
+    return np.where(np.abs(gdif) < 1.0e-4 * np.abs(gav), rf, rfn)
+
+
+def ratintn(f, g, z):
+    """ratintn.py:4-23: sum(ratcen(f, g) * (z[1:-1] - z[0:-2]))."""
+    zdif = z[1:-1] - z[0:-2]
+    return np.sum(ratcen(f, g) * zdif, axis=-1)
+
+
+def chi_table(vx, fe):
+    """The Re(chi_e) table W on xi2 (form_factor.py:263-268).  Returns (W[1640], ratmod[1024])."""
+    xi1, xi2 = xi_grids()
+    ratmod = np.exp(interp_hermite(xi1, vx, np.log(fe), -50.0, -50.0))
+    ratdf = gradient_uniform(ratmod, xi1[1] - xi1[0])
+    W = ratintn(ratdf, xi1[None, :] - xi2[:, None], xi1)
+    return W, ratmod
+
+
+_W_CACHE: dict = {}
+
+
+def chi_table_cached(vx, fe):
+    key = (vx.tobytes(), fe.tobytes())
+    if key not in _W_CACHE:
+        if len(_W_CACHE) > 64:
+            _W_CACHE.clear()
+        _W_CACHE[key] = chi_table(vx, fe)[0]
+    return _W_CACHE[key]
+
+
+# ---------------------------------------------------------------------------------------------
+# distribution functions  (tsadar/core/modules/distribution_functions/base.py:136-151, 237-294)
+# ---------------------------------------------------------------------------------------------
+def velocity_grid(nvx):
+    """base.py:149-151."""
+    vmax = 6.0
+    dv = 2 * vmax / nvx
+    return np.linspace(-vmax + dv / 2, vmax - dv / 2, nvx)
+
+
+DLM_M_AXIS = np.linspace(2, 5, 31)  # base.py:270
+
+
+def dlm_projection(x, m):
+    """1-D projection of the unit-normalised 3-D super-Gaussian (the content of the reference's
+    missing table file ``DLM_x_-3_-10_10_m_-1_2_5.mat``):
+
+        f3(v) = m / (4 pi a^3 Gamma(3/m)) exp(-(v/a)^m),  a = alpha*v_th, v_th = sqrt(2),
+        alpha = sqrt(3 Gamma(3/m) / (2 Gamma(5/m)))
+        f1(x) = int_0^inf 2 pi r f3(sqrt(x^2+r^2)) dr = 2 pi int_|x|^inf u f3(u) du
+              = (a^2/m) Gamma(2/m) Q(2/m, (|x|/a)^m) * 2 pi * m / (4 pi a^3 Gamma(3/m))
+
+    (Q = regularised upper incomplete gamma).  The substitution u^2 = x^2 + r^2 makes the radial
+    integral closed-form, so no quadrature is needed."""
+    vth = np.sqrt(2.0)
+    alpha = np.sqrt(3.0 * _gamma(3.0 / m) / (2.0 * _gamma(5.0 / m)))
+    a = alpha * vth
+    cst = m / (4.0 * np.pi * a**3 * _gamma(3.0 / m))
+    return 2.0 * np.pi * cst * (a**2 / m) * _gamma(2.0 / m) * _gammaincc(2.0 / m, (np.abs(x) / a) ** m)
+
+
+@lru_cache(maxsize=None)
+def dlm_table(nvx):
+    """f_vx_m of base.py:266-272: the 20001x31 table (x = linspace(-10, 10, 20001)) linearly
+    interpolated onto vx.  Only the two table nodes bracketing each vx are ever needed."""
+    vx = velocity_grid(nvx)
+    x_ax = np.linspace(-10, 10, 20001)
+    i = np.clip(np.searchsorted(x_ax, vx, side="right"), 1, len(x_ax) - 1)
+    x0, x1 = x_ax[i - 1], x_ax[i]
+    tab = np.empty((nvx, len(DLM_M_AXIS)))
+    for k, m in enumerate(DLM_M_AXIS):
+        f0, f1 = dlm_projection(x0, m), dlm_projection(x1, m)
+        tab[:, k] = f0 + ((vx - x0) / (x1 - x0)) * (f1 - f0)
+    return tab
+
+
+def dlm_fe(m, nvx):
+    """DLM1V.__call__ (base.py:277-294): linear interpolation in m, then /sum/dv."""
+    vx = velocity_grid(nvx)
+    tab = dlm_table(nvx)
+    f = np.array([np.interp(m, DLM_M_AXIS, tab[i]) for i in range(nvx)])
+    return f / np.sum(f) / (vx[1] - vx[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter transform  (tsadar/core/modules/ts_params.py:61-104, 202-218, 308-350, 459-495, 543-603)
+# ---------------------------------------------------------------------------------------------
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def inv_act(x):
+    """ts_params.py:344 / base.py:259 -- NOT the inverse of the sigmoid."""
+    return np.log(1e-2 + x / (1 - x + 1e-2))
+
+
+GENERAL_KEYS = ["lam", "amp1", "amp2", "amp3", "ne_gradient", "Te_gradient", "ud", "Va"]
+
+
+def ion_species(cfg_params):
+    return [k for k in cfg_params.keys() if "ion" in k]
+
+
+def init_normed_params(cfg_params, batch_size, activate=True):
+    """The normalised leaves a ``ThomsonParams(cfg, batch_size, batch=True, activate)`` holds
+    (ts_params.py:84-104, 261-306, 422-457; DLM m: base.py:252-262).  Returns {name: array[B]};
+    ion leaves are named ``Ti_1``, ``Z_1``, ``A_1``, ``fract_1`` ..."""
+    out = {}
+
+    def one(pc, scale, shift, active):
+        v = (pc["val"] - shift) / scale
+        if activate and active:
+            v = inv_act(v)
+        return np.full(batch_size, v, dtype=np.float64)
+
+    el = cfg_params["electron"]
+    for k in ["Te", "ne"]:
+        out[k] = one(el[k], el[k]["ub"] - el[k]["lb"], el[k]["lb"], el[k]["active"])
+    fe = el["fe"]
+    if fe["type"].casefold() == "dlm":
+        out["m"] = one(fe["params"]["m"], 3.0, 2.0, fe.get("active", False))
+    for s, sp in enumerate(ion_species(cfg_params)):
+        ic = cfg_params[sp]
+        for k in ["Ti", "Z"]:
+            out[f"{k}_{s+1}"] = one(ic[k], ic[k]["ub"] - ic[k]["lb"], ic[k]["lb"], ic[k]["active"])
+        out[f"A_{s+1}"] = np.full(batch_size, float(ic["A"]["val"]))
+        out[f"fract_{s+1}"] = one(ic["fract"], 1.0, 0.0, ic["fract"]["active"])
+    g = cfg_params["general"]
+    for k in GENERAL_KEYS:
+        out[k] = one(g[k], g[k]["ub"] - g[k]["lb"], g[k]["lb"], g[k]["active"])
+    return out
+
+
+def physical_params(cfg_params, normed, activate=True):
+    """``ThomsonParams.__call__`` (ts_params.py:583-603): activation + affine map for every leaf,
+    ion fractions renormalised to sum 1, optional Ti tying (``renormalize_ions`` :543-563)."""
+    def act(pc_active, x):
+        return sigmoid(x) if (activate and pc_active) else x
+
+    el = cfg_params["electron"]
+    phys = {}
+    for k in ["Te", "ne"]:
+        phys[k] = act(el[k]["active"], normed[k]) * (el[k]["ub"] - el[k]["lb"]) + el[k]["lb"]
+    if "m" in normed:
+        phys["m"] = act(el["fe"].get("active", False), normed["m"]) * 3.0 + 2.0
+    species = ion_species(cfg_params)
+    fsum = 0.0
+    for s, sp in enumerate(species):
+        ic = cfg_params[sp]
+        for k in ["Ti", "Z"]:
+            phys[f"{k}_{s+1}"] = act(ic[k]["active"], normed[f"{k}_{s+1}"]) * (ic[k]["ub"] - ic[k]["lb"]) + ic[k]["lb"]
+        phys[f"A_{s+1}"] = normed[f"A_{s+1}"]
+        phys[f"fract_{s+1}"] = act(ic["fract"]["active"], normed[f"fract_{s+1}"])
+        if s > 0 and ic["Ti"].get("same", False):
+            phys[f"Ti_{s+1}"] = phys["Ti_1"]
+        fsum = fsum + phys[f"fract_{s+1}"]
+    for s in range(len(species)):
+        phys[f"fract_{s+1}"] = phys[f"fract_{s+1}"] / fsum
+    g = cfg_params["general"]
+    for k in GENERAL_KEYS:
+        phys[k] = act(g[k]["active"], normed[k]) * (g[k]["ub"] - g[k]["lb"]) + g[k]["lb"]
+    return phys
+
+
+# ---------------------------------------------------------------------------------------------
+# FormFactor.__call__  (tsadar/core/physics/form_factor.py:163-298), one lineout
+# ---------------------------------------------------------------------------------------------
+def form_factor(lam_range, npts, lam_shift, sa_deg, num_grad_points, p, vx, fe, W=None):
+    """One lineout.  ``p``: dict of physical scalars Te, ne, lam, Va, ud, ne_gradient, Te_gradient
+    and lists Ti, Z, A, fract.  Returns (P[G, npts, ntheta], lam_cm[npts])."""
+    xi1, xi2 = xi_grids()
+    zr_tab, zi_tab = zprime_tables()
+    G = num_grad_points
+    lam_axis = np.linspace(lam_range[0], lam_range[1], npts)
+    omgL_num = 2 * np.pi * 1e7 * C
+    omgs = (2e7 * np.pi * C / lam_axis)[None, :, None]  # :134-135
+
+    ne = 1.0e20 * p["ne"] * np.linspace(1 - p["ne_gradient"] / 200, 1 + p["ne_gradient"] / 200, G)  # :182-190
+    Te = p["Te"] * np.linspace(1 - p["Te_gradient"] / 200, 1 + p["Te_gradient"] / 200, G)  # :191-195
+    lam = p["lam"] + lam_shift
+    A = np.asarray(p["A"], dtype=np.float64)
+    Z = np.asarray(p["Z"], dtype=np.float64).reshape(1, 1, 1, -1)
+    Ti = np.asarray(p["Ti"], dtype=np.float64)
+    fract = np.asarray(p["fract"], dtype=np.float64).reshape(1, 1, 1, -1)
+    Va = p["Va"] * 1e6
+    ud = p["ud"] * 1e6
+    Mi = (A * MP).reshape(1, 1, 1, -1)
+    sarad = (np.asarray(sa_deg, dtype=np.float64) * np.pi / 180).reshape(1, 1, -1)
+    omgL = omgL_num / lam
+
+    omgpe = C0 * np.sqrt(ne[:, None, None])  # :215
+    omg = omgs - omgL
+    ks = np.sqrt(omgs**2 - omgpe**2) / C
+    kL = np.sqrt(omgL**2 - omgpe**2) / C
+    k = np.sqrt(ks**2 + kL**2 - 2 * ks * kL * np.cos(sarad))
+    omgdop = omg - k * Va
+
+    vTe = np.sqrt(Te[:, None, None] / ME)
+    klde = (vTe / omgpe) * k
+
+    Zbar = np.sum(Z * fract)
+    ni = fract * ne[:, None, None, None] / Zbar
+    omgpi = C0 * Z * np.sqrt(ni * ME / Mi)
+    vTi = np.sqrt(Ti.reshape(1, 1, 1, -1) / Mi)
+    kldi = (vTi / omgpi) * k[..., None]
+
+    xii = (1.0 / (np.sqrt(2.0) * vTi)) * (omgdop / k)[..., None]  # :243
+    ZpiR = interp_linear(xii, xi2, zr_tab, left=xii**-2, right=xii**-2)  # :247
+    ZpiI = interp_linear(xii, xi2, zi_tab, left=0.0, right=0.0)
+    chiI = np.sum(-0.5 / kldi**2 * (ZpiR + 1j * ZpiI), axis=3)
+
+    xie = omgdop / (k * vTe) - ud / vTe  # :253
+    lnfe = np.log(fe)
+    fe_vphi = np.exp(interp_hermite(xie, vx, lnfe, -50.0, -50.0))  # :256
+
+    df = np.diff(fe_vphi, axis=1) / np.diff(xie, axis=1)  # :258
+    df = np.concatenate([df, np.zeros((G, 1, df.shape[2]))], axis=1)
+    chiEI = np.pi / klde**2 * 1j * df
+
+    if W is None:
+        W = chi_table_cached(vx, fe)  # :263-268
+    chiERrat = interp_linear(xie, xi2, W)  # :270 (clamps to the end values)
+    chiERrat = -1.0 / klde**2 * chiERrat
+
+    chiE = chiERrat + chiEI
+    eps = 1.0 + chiE + chiI
+
+    ion_fact = fract * Z**2 / Zbar / vTi  # :277
+    ion_comp = ion_fact * (np.abs(chiE[..., None]) ** 2 * np.exp(-(xii**2)) / np.sqrt(2 * np.pi))
+    ele_comp = np.abs(1.0 + chiI) ** 2 * fe_vphi / vTe
+    S_ion = np.sum(1.0 / k[..., None] * ion_comp / np.abs(eps[..., None]) ** 2, axis=3)
+    S_ele = 1.0 / k * ele_comp / np.abs(eps) ** 2
+    PsOmg = (S_ion + S_ele) * (1 + 2 * omgdop / omgL) * RE**2 * ne[:, None, None]
+    lams = 2 * np.pi * C / omgs
+    PsLam = PsOmg * 2 * np.pi * C / lams**2
+    return PsLam, lams[0, :, 0]
+
+
+# ---------------------------------------------------------------------------------------------
+# FitModel  (tsadar/core/physics/generate_spectra.py:139-220), one lineout
+# ---------------------------------------------------------------------------------------------
+def _angle_weights(sa):
+    """``scattering_angles["weights"][0]`` (generate_spectra.py:165,197): the weight
+    row when ``weights`` is [n_lineouts, ntheta], the scalar first weight when it is 1-D."""
+    w = np.asarray(sa["weights"])
+    return w[0]
+
+
+def model_spectrum(cfg, sa, p, vx, fe, feature, W=None):
+    """``ion_spectrum`` (feature "ion") / ``electron_spectrum`` (feature "ele").  Returns
+    (lam_nm[npts], modl[npts])."""
+    other = cfg["other"]
+    G = cfg["parameters"]["general"]["Te_gradient"]["num_grad_points"]
+    if feature == "ion":
+        rng, shift = other["lamrangI"], 0.0
+    else:
+        rng, shift = other["lamrangE"], cfg["data"]["ele_lam_shift"]
+    P, lam_cm = form_factor(rng, other["npts"], shift, sa["sa"], G, p, vx, fe, W)
+    lam_nm = lam_cm * 1e7
+    modl = np.sum(np.mean(P, axis=0) * _angle_weights(sa), axis=1)
+    if feature == "ele":
+        if other["iawoff"] and (other["lamrangE"][0] < p["lam"] < other["lamrangE"][1]):
+            raise NotImplementedError("iawoff is not restated (it cannot run under vmap in the reference)")
+        filt = other["iawfilter"]
+        if filt[0]:
+            fb, fr = filt[3] - filt[2] / 2, filt[3] + filt[2] / 2
+            if other["lamrangE"][0] < fr and other["lamrangE"][1] > fb:
+                modl = np.where((fb < lam_nm) & (fr > lam_nm), modl * 10.0 ** (-filt[1]), modl)
+    return lam_nm, modl
+
+
+# ---------------------------------------------------------------------------------------------
+# instrument response  (tsadar/core/physics/irf.py:50-132)
+# ---------------------------------------------------------------------------------------------
+def _gauss_same(lam, modl, stddev):
+    origin = (np.amax(lam) + np.amin(lam)) / 2.0
+    g = (1.0 / (stddev * np.sqrt(2.0 * np.pi))) * np.exp(-((lam - origin) ** 2.0) / (2.0 * stddev**2.0))
+    y = np.convolve(modl, g, "same")
+    return (np.amax(modl) / np.amax(y)) * y
+
+
+def add_electron_irf(cfg, lam, modl, amps, p):
+    """irf.py:90-132 (norm == 0 branch and the norm > 0 ``where``)."""
+    phys = cfg["other"]["PhysParams"]
+    y = _gauss_same(lam, modl, phys["widIRF"]["spect_stddev_ele"])
+    if phys["norm"] > 0:
+        y = np.where(
+            lam < p["lam"],
+            p["amp1"] * (y / np.amax(y[lam < p["lam"]])),
+            p["amp2"] * (y / np.amax(y[lam > p["lam"]])),
+        )
+    y = np.average(y.reshape(1024, -1), axis=1)
+    if phys["norm"] == 0:
+        lam = np.average(lam.reshape(1024, -1), axis=1)
+        y = amps * y / np.amax(y)
+        y = np.where(lam < p["lam"], p["amp1"] * y, p["amp2"] * y)
+    return lam, y
+
+
+def add_ion_irf(cfg, lam, modl, amps, p):
+    """irf.py:50-87."""
+    phys = cfg["other"]["PhysParams"]
+    std = phys["widIRF"]["spect_stddev_ion"]
+    if std:
+        y = _gauss_same(lam, modl, std)
+        y = np.average(y.reshape(1024, -1), axis=1)
+        if phys["norm"] == 0:
+            lam = np.average(lam.reshape(1024, -1), axis=1)
+            y = p["amp3"] * amps * y / np.amax(y)
+    else:
+        y = modl
+    return lam, y
+
+
+# ---------------------------------------------------------------------------------------------
+# ThomsonScatteringDiagnostic.__call__  (tsadar/core/thomson_diagnostic.py:109-142)
+# ---------------------------------------------------------------------------------------------
+def lineout_params(phys, b, n_ion):
+    """Slice lineout ``b`` out of the batched physical-parameter dict."""
+    def at(v):
+        v = np.asarray(v)
+        return float(v[b]) if v.ndim else float(v)
+
+    p = {k: at(phys[k]) for k in ["Te", "ne", "lam", "amp1", "amp2", "amp3", "ne_gradient", "Te_gradient", "ud", "Va"]}
+    for k in ["Ti", "Z", "A", "fract"]:
+        p[k] = [at(phys[f"{k}_{s+1}"]) for s in range(n_ion)]
+    if "m" in phys:
+        p["m"] = at(phys["m"])
+    return p
+
+
+def lineout_fe(cfg, p, fe_batch=None, b=0):
+    fecfg = cfg["parameters"]["electron"]["fe"]
+    nvx = fecfg["nvx"]
+    vx = velocity_grid(nvx)
+    if fe_batch is not None:
+        fe = np.asarray(fe_batch)
+        fe = fe[b] if fe.ndim == 2 else fe
+    elif fecfg["type"].casefold() == "dlm":
+        fe = dlm_fe(p["m"], nvx)
+    else:
+        raise NotImplementedError(fecfg["type"])
+    return vx, fe
+
+
+def ts_diag(cfg, sa, normed, batch, activate=True, fe_batch=None):
+    """Returns (ThryE[B,1024], ThryI[B,1024], lamE[B,1024], lamI[B,1024]); a feature that is not
+    loaded returns zeros like the reference (generate_spectra.py:166-168, 217-219)."""
+    cfgp = cfg["parameters"]
+    phys = physical_params(cfgp, normed, activate)
+    n_ion = len(ion_species(cfgp))
+    B = len(np.atleast_1d(normed["Te"]))
+    ext = cfg["other"]["extraoptions"]
+
+    def col(name, b):
+        v = np.asarray(batch[name], dtype=np.float64)
+        if v.ndim == 0:
+            return v
+        v = v[b] if v.shape[0] == B else v
+        return np.squeeze(v) if v.ndim == 1 and v.shape[0] == 1 else v
+
+    outE, outI, lamE, lamI = [], [], [], []
+    for b in range(B):
+        p = lineout_params(phys, b, n_ion)
+        vx, fe = lineout_fe(cfg, p, fe_batch, b)
+        W = chi_table_cached(vx, fe)
+        if ext["load_ion_spec"]:
+            lam, modl = model_spectrum(cfg, sa, p, vx, fe, "ion", W)
+            lam, y = add_ion_irf(cfg, lam, modl, col("i_amps", b), p)
+            outI.append(y + col("noise_i", b))
+            lamI.append(lam)
+        if ext["load_ele_spec"]:
+            lam, modl = model_spectrum(cfg, sa, p, vx, fe, "ele", W)
+            lam, y = add_electron_irf(cfg, lam, modl, col("e_amps", b), p)
+            outE.append(y + col("noise_e", b))
+            lamE.append(lam)
+    z = np.zeros((B, 1024))
+    return (
+        np.array(outE) if outE else z,
+        np.array(outI) if outI else z,
+        np.array(lamE) if lamE else z,
+        np.array(lamI) if lamI else z,
+    )
+
+
+# ---------------------------------------------------------------------------------------------
+# LossFunction  (tsadar/inverse/loss_function.py:190-267, 269-341, 364-418)
+# ---------------------------------------------------------------------------------------------
+def loss_functional(d, t, uncert, method):
+    """loss_function.py:386-418."""
+    if method == "l1":
+        return np.abs(d - t) / uncert
+    if method == "l2":
+        return np.square(d - t) / uncert
+    if method == "log-cosh":
+        return np.log(np.cosh(d - t))
+    if method == "poisson":
+        return t - d * np.log(t)
+    raise NotImplementedError(method)
+
+
+def fit_masks(cfg, lamE, lamI):
+    """The wavelength-range masks of calc_ei_error (loss_function.py:224-259)."""
+    r = cfg["data"]["fit_rng"]
+    iaw = ((lamI > r["iaw_min"]) & (lamI < r["iaw_cf_min"])) | ((lamI > r["iaw_cf_max"]) & (lamI < r["iaw_max"]))
+    blue = (lamE > r["blue_min"]) & (lamE < r["blue_max"])
+    red = (lamE > r["red_min"]) & (lamE < r["red_max"])
+    return iaw, blue, red
+
+
+def calc_ei_error(cfg, batch, ThryI, lamI, ThryE, lamE, uncert, reduce_func):
+    ext = cfg["other"]["extraoptions"]
+    method = cfg["optimizer"]["loss_method"]
+    iaw, blue, red = fit_masks(cfg, lamE, lamI)
+    i_err, e_err = 0.0, 0.0
+    sq = {"ele": np.zeros_like(np.asarray(batch["e_data"], dtype=np.float64)),
+          "ion": np.zeros_like(np.asarray(batch["i_data"], dtype=np.float64))}
+    if ext["fit_IAW"]:
+        e = np.where(iaw, loss_functional(batch["i_data"], ThryI, uncert[0], method), np.nan)
+        i_err = i_err + reduce_func(e)
+        sq["ion"] = np.nan_to_num(e)
+    if ext["fit_EPWb"]:
+        e = np.where(blue, loss_functional(batch["e_data"], ThryE, uncert[1], method), np.nan)
+        e_err = e_err + reduce_func(e)
+        sq["ele"] = sq["ele"] + np.nan_to_num(e)
+    if ext["fit_EPWr"]:
+        e = np.where(red, loss_functional(batch["e_data"], ThryE, uncert[1], method), np.nan)
+        e_err = e_err + reduce_func(e)
+        if ext["fit_EPWb"]:
+            e_err = e_err * 0.5
+        sq["ele"] = sq["ele"] + np.nan_to_num(e)
+    return i_err, e_err, sq
+
+
+def loss_norms(cfg, dummy_batch):
+    """loss_function.py:88-92."""
+    if cfg["optimizer"]["y_norm"]:
+        return float(np.amax(dummy_batch["i_data"])), float(np.amax(dummy_batch["e_data"]))
+    return 1.0, 1.0
+
+
+def loss(cfg, sa, normed, batch, i_norm, e_norm, activate=True, fe_batch=None):
+    """``LossFunction.__loss__`` (loss_function.py:364-373): total scalar loss, nanmean reduce."""
+    ThryE, ThryI, lamE, lamI = ts_diag(cfg, sa, normed, batch, activate, fe_batch)
+    i_err, e_err, _ = calc_ei_error(cfg, batch, ThryI, lamI, ThryE, lamE, [i_norm**2, e_norm**2], np.nanmean)
+    return cfg["data"]["ion_loss_scale"] * i_err + e_err, ThryE, ThryI
+
+
+def array_loss(cfg, sa, normed, batch, activate=True, fe_batch=None):
+    """``LossFunction.post_loss`` (loss_function.py:375-384): per-lineout nanmean(axis=1), the
+    denominators are the theory spectra themselves (calc_loss :320-321)."""
+    ThryE, ThryI, lamE, lamI = ts_diag(cfg, sa, normed, batch, activate, fe_batch)
+    with np.errstate(all="ignore"):
+        i_err, e_err, sq = calc_ei_error(cfg, batch, ThryI, lamI, ThryE, lamE, [ThryI, ThryE],
+                                         lambda a: np.nanmean(a, axis=1))
+    return cfg["data"]["ion_loss_scale"] * i_err + e_err, sq, ThryE, ThryI
+
+
+def fd_gradient(cfg, sa, normed, batch, i_norm, e_norm, names, h=1e-6, activate=True, fe_batch=None):
+    """Central finite differences of ``loss`` w.r.t. the normalised leaves in ``names``;
+    returns {name: array[B]}.  O(B * len(names)) loss evaluations -- small cases only."""
+    out = {}
+    B = len(normed["Te"])
+    for nm in names:
+        g = np.zeros(B)
+        for b in range(B):
+            up = {k: np.array(v, dtype=np.float64, copy=True) for k, v in normed.items()}
+            dn = {k: np.array(v, dtype=np.float64, copy=True) for k, v in normed.items()}
+            up[nm][b] += h
+            dn[nm][b] -= h
+            lu = loss(cfg, sa, up, batch, i_norm, e_norm, activate, fe_batch)[0]
+            ld = loss(cfg, sa, dn, batch, i_norm, e_norm, activate, fe_batch)[0]
+            g[b] = (lu - ld) / (2 * h)
+        out[nm] = g
+    return out
