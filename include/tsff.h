@@ -1,0 +1,193 @@
+/*
+ * tsff.h -- C ABI of libtsff.so, the MI355X (gfx950) Thomson-scattering form-factor engine.
+ *
+ * Drop-in boundary for ONE hot path of ergodicio/tsadar: the S(k,w) forward model and its
+ * parameter gradient over a batch of lineouts.  Citations are file:line in the reference tree.
+ *
+ *   reference interface                                            replaced by
+ *   -------------------------------------------------------------  ---------------------------
+ *   FormFactor.__init__            core/physics/form_factor.py:120-161      tsff_create
+ *   FormFactor.__call__            core/physics/form_factor.py:163-298      tsff_form_factor
+ *   ratintn / ratcen               core/physics/ratintn.py:4-52             tsff_chi_table
+ *   DLM1V.__call__                 core/modules/distribution_functions/base.py:277-294
+ *                                                                           (fe_mode TSFF_FE_DLM)
+ *   ThomsonParams.__call__         core/modules/ts_params.py:583-603        (inside every call)
+ *   ThomsonScatteringDiagnostic.__call__  core/thomson_diagnostic.py:109-142  tsff_forward
+ *     FitModel.ion/electron_spectrum core/physics/generate_spectra.py:139-220
+ *     add_ion_IRF / add_electron_IRF core/physics/irf.py:50-132
+ *   LossFunction.vg_loss / __loss__ inverse/loss_function.py:128-168,364-373  tsff_loss_grad
+ *   LossFunction.array_loss (post_loss) inverse/loss_function.py:375-384      tsff_array_loss
+ *
+ * Conventions
+ *   - every array pointer in a *call* is a DEVICE pointer (hipMalloc'ed or a torch CUDA tensor);
+ *     every pointer inside tsff_config is a HOST pointer and is copied by tsff_create;
+ *   - all arithmetic and all arrays are float64, row-major;
+ *   - the caller owns every buffer; the library never frees caller memory;
+ *   - calls are asynchronous on the handle's stream (tsff_set_stream); the caller synchronises;
+ *   - return value 0 = success, negative = error, text via tsff_last_error();
+ *   - a handle is bound to the device that was current at tsff_create; handles are not thread-safe,
+ *     the library is re-entrant across handles.
+ *   - no CPU fallback exists: without a HIP device every entry point fails.
+ */
+#ifndef TSFF_H
+#define TSFF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSFF_ABI_VERSION 1
+
+/* ---- parameter slots of one lineout: params[b][TSFF_NP(n_ion)] (normalised leaves of the
+ * reference's ThomsonParams pytree, core/modules/ts_params.py:49-60,395-420,253-262) ---------- */
+enum {
+  TSFF_P_TE = 0,
+  TSFF_P_NE = 1,
+  TSFF_P_M = 2, /* DLM super-Gaussian order (base.py:252-262); ignored unless fe_mode == DLM */
+  TSFF_P_LAM = 3,
+  TSFF_P_AMP1 = 4,
+  TSFF_P_AMP2 = 5,
+  TSFF_P_AMP3 = 6,
+  TSFF_P_NE_GRADIENT = 7,
+  TSFF_P_TE_GRADIENT = 8,
+  TSFF_P_UD = 9,
+  TSFF_P_VA = 10,
+  TSFF_P_ION0 = 11 /* then per ion species s: +4s+0 Ti, +1 Z, +2 A, +3 fract */
+};
+#define TSFF_ION_TI 0
+#define TSFF_ION_Z 1
+#define TSFF_ION_A 2
+#define TSFF_ION_FRACT 3
+#define TSFF_NP(n_ion) (TSFF_P_ION0 + 4 * (n_ion))
+#define TSFF_MAX_ION 4
+#define TSFF_MAX_ANGLES 64
+#define TSFF_NBINS 1024 /* irf.py:74,124: reshape(1024, -1) */
+#define TSFF_NXI2 1640  /* form_factor.py:138 */
+#define TSFF_NXI1 1024  /* form_factor.py:137 */
+#define TSFF_DLM_NM 31  /* base.py:270 */
+
+enum { TSFF_FE_SHARED = 0, TSFF_FE_PER_LINEOUT = 1, TSFF_FE_DLM = 2 };
+enum { TSFF_LOSS_L2 = 0, TSFF_LOSS_L1 = 1, TSFF_LOSS_LOGCOSH = 2, TSFF_LOSS_POISSON = 3 };
+enum { TSFF_FEATURE_ELE = 0, TSFF_FEATURE_ION = 1 };
+
+typedef struct tsff_config {
+  int32_t abi_version; /* = TSFF_ABI_VERSION */
+
+  /* wavelength grids (form_factor.py:132-135; cfg other.lamrangE/lamrangI/npts) */
+  double lamrangE[2];
+  double lamrangI[2];
+  int32_t npts;         /* = 1024 * points_per_pixel */
+  int32_t load_ele;     /* other.extraoptions.load_ele_spec */
+  int32_t load_ion;     /* other.extraoptions.load_ion_spec */
+  double ele_lam_shift; /* data.ele_lam_shift (form_factor.py:196) */
+
+  /* scattering angles and the row `weights[0]` (generate_spectra.py:165,197) */
+  int32_t n_angles;
+  const double *sa_deg;     /* [n_angles] */
+  const double *sa_weights; /* [n_angles] */
+
+  int32_t num_grad_points; /* parameters.general.*_gradient.num_grad_points */
+  int32_t n_ion;
+
+  /* electron distribution function */
+  int32_t nvx;
+  int32_t fe_mode;
+  const double *fe_shared; /* [nvx], TSFF_FE_SHARED */
+  const double *dlm_table; /* [nvx][TSFF_DLM_NM] = f_vx_m of base.py:272, TSFF_FE_DLM */
+
+  /* static grids/tables of FormFactor.__init__ (form_factor.py:137-139) */
+  const double *xi1;       /* [TSFF_NXI1] */
+  const double *xi2;       /* [TSFF_NXI2] */
+  const double *zprime_re; /* [TSFF_NXI2] rdWT.txt interpolated on xi2 */
+  const double *zprime_im; /* [TSFF_NXI2] */
+
+  /* instrument response (irf.py:50-132): Gaussian taps g[d], y[j] = sum_d g[d] x[j-d],
+   * d = tap_dmin .. tap_dmin + n_taps - 1 (the reference's "same" alignment) */
+  int32_t n_taps_ele;
+  int32_t tap_dmin_ele;
+  const double *taps_ele;
+  int32_t n_taps_ion; /* 0 <=> spect_stddev_ion == 0 (irf.py:85: ThryI = modlI, npts must be 1024) */
+  int32_t tap_dmin_ion;
+  const double *taps_ion;
+  int32_t norm; /* other.PhysParams.norm; only 0 is implemented */
+
+  /* iawfilter (generate_spectra.py:210-216) as a per-sample multiplier on the EPW grid */
+  const double *ele_filter; /* [npts] or NULL (= all ones) */
+
+  /* parameter transform (ts_params.py:329-350): phys = act(x) * scale + shift */
+  const double *p_scale;        /* [NP] */
+  const double *p_shift;        /* [NP] */
+  const uint8_t *p_sigmoid;     /* [NP] 1 = sigmoid activation, 0 = identity */
+  uint8_t ti_same[TSFF_MAX_ION]; /* ion-k.Ti.same (ts_params.py:557-558) */
+
+  /* loss (loss_function.py:190-267, 386-418) */
+  int32_t loss_method;
+  const uint8_t *mask_ele; /* [1024] bit0: blue range fitted, bit1: red range fitted */
+  const uint8_t *mask_ion; /* [1024] bit0: IAW range fitted */
+} tsff_config;
+
+typedef struct tsff_handle tsff_handle;
+
+/* lifecycle ------------------------------------------------------------------------------- */
+int tsff_create(const tsff_config *cfg, tsff_handle **out);
+void tsff_destroy(tsff_handle *h);
+const char *tsff_last_error(const tsff_handle *h); /* h == NULL: last tsff_create failure */
+int tsff_abi_version(void);
+int tsff_set_stream(tsff_handle *h, void *hip_stream);
+/* make sure the workspace holds B lineouts (calls grow it lazily; not inside graph capture) */
+int tsff_reserve(tsff_handle *h, int32_t B);
+
+/* wavelength axes (HOST pointers): the binned axes lamAxisE/lamAxisI [1024] in nm that the
+ * reference returns per lineout (irf.py:75,125) -- they do not depend on the parameters. */
+int tsff_get_axes(const tsff_handle *h, double *lamE, double *lamI);
+
+/* Re(chi_e) table W[1640] and the Hermite table of ln fe for `n` distribution functions
+ * fe[n][nvx] (form_factor.py:263-268 + ratintn.py).  W: [n][1640]. */
+int tsff_chi_table(tsff_handle *h, const double *fe, int32_t n, double *W);
+
+/* FormFactor.__call__ for B lineouts without the instrument chain: P[B][G][npts][n_angles]
+ * (W/m^... arbitrary units of the reference).  `phys` holds PHYSICAL parameters [B][NP]
+ * (no activation); fe is [B][nvx] (PER_LINEOUT), ignored otherwise. */
+int tsff_form_factor(tsff_handle *h, int32_t feature, const double *phys, const double *fe,
+                     int32_t B, double *P);
+
+/* ThomsonScatteringDiagnostic.__call__: ThryE/ThryI [B][1024].  noise_* may be NULL (= 0).
+ * params: normalised leaves [B][NP]; fe: [B][nvx] when fe_mode == PER_LINEOUT else NULL. */
+int tsff_forward(tsff_handle *h, const double *params, const double *fe, const double *e_amps,
+                 const double *i_amps, const double *noise_e, const double *noise_i, int32_t B,
+                 double *ThryE, double *ThryI);
+
+/* LossFunction.vg_loss: value and gradient.
+ *   weights[3] (HOST): w_iaw, w_blue, w_red -- the factor each masked sum carries in the total
+ *   loss, i.e. ion_loss_scale/(N_iaw*i_norm^2), c/(N_blue*e_norm^2), c/(N_red*e_norm^2) with N_* the
+ *   number of fitted samples over the WHOLE (global, all ranks) batch and c = 1/2 when both EPW
+ *   ranges are fitted (loss_function.py:262-264, 335-338).
+ *   loss_terms[3] (device): un-weighted masked sums  S_iaw, S_blue, S_red  over these B lineouts;
+ *   total loss = sum_k weights[k] * S_k (summed over ranks).
+ *   grad (device) [B][NP]: d(total loss)/d(params[b][slot]) for slots with grad_mask[slot] != 0
+ *   (HOST uint8 [NP]), 0 elsewhere.  ThryE/ThryI may be NULL. */
+int tsff_loss_grad(tsff_handle *h, const double *params, const double *fe, const double *e_data,
+                   const double *i_data, const double *e_amps, const double *i_amps,
+                   const double *noise_e, const double *noise_i, int32_t B,
+                   const double *weights, const uint8_t *grad_mask, double *loss_terms,
+                   double *grad, double *ThryE, double *ThryI);
+
+/* LossFunction.array_loss: per-lineout masked sums with the theory spectrum as denominator
+ * ((d-t)^2/t, loss_function.py:320-321).  sums [B][3] = S_iaw, S_blue, S_red per lineout;
+ * sqdev_e / sqdev_i [B][1024] (may be NULL) = nan_to_num'ed error arrays (:238,250,264). */
+int tsff_array_loss(tsff_handle *h, const double *params, const double *fe, const double *e_data,
+                    const double *i_data, const double *e_amps, const double *i_amps,
+                    const double *noise_e, const double *noise_i, int32_t B, double *sums,
+                    double *sqdev_e, double *sqdev_i, double *ThryE, double *ThryI);
+
+/* timing of the last tsff_forward / tsff_loss_grad main kernel, measured with HIP events on the
+ * handle's stream (enable first; adds two event records per call). */
+int tsff_enable_timing(tsff_handle *h, int32_t on);
+int tsff_last_kernel_ms(tsff_handle *h, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSFF_H */

@@ -1,0 +1,214 @@
+"""GPU parity tests: every call goes through the C ABI of libtsff.so (ctypes) and is compared with
+the CPU oracle on the same seeded inputs.  Floating point (float64): tolerance 1e-5 relative as
+BASELINE.json's north_star states; most checks are far tighter and say so."""
+import copy
+
+import numpy as np
+import pytest
+
+import decks
+import util
+from oracle import tsadar_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # north_star tolerance
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch
+
+
+def _engine(cfg, sa, **kw):
+    from tsadar_amd.engine import Engine
+
+    return Engine(cfg, sa, **kw)
+
+
+def test_chi_table_matches_ratintn(torch_mod):
+    """a8: W[1640] of k_fe_prepare vs oracle ratintn, Maxwellian and super-Gaussian f_e."""
+    cfg = decks.deck_fit()
+    eng = _engine(cfg, util.sa_fit(1))
+    nvx = cfg["parameters"]["electron"]["fe"]["nvx"]
+    vx = orc.velocity_grid(nvx)
+    fes = np.stack([orc.dlm_fe(m, nvx) for m in (2.0, 2.5158, 3.7, 5.0)])
+    W = eng.chi_table(fes).cpu().numpy()
+    for k in range(fes.shape[0]):
+        Wo, _ = orc.chi_table(vx, fes[k])
+        err = np.max(np.abs(W[k] - Wo)) / np.max(np.abs(Wo))
+        assert err < 1e-11, (k, err)
+
+
+@pytest.mark.parametrize("feature", [0, 1])
+def test_form_factor_matches_oracle(torch_mod, feature):
+    """a4-a10: raw FormFactor.__call__ output P[G, npts, ntheta] for random plasma conditions."""
+    cfg = decks.deck_fit()
+    B = 4
+    sa = util.sa_fit(B)
+    eng = _engine(cfg, sa)
+    normed = util.random_lineouts(cfg, B, seed=11 + feature)
+    phys = orc.physical_params(cfg["parameters"], normed, True)
+    X = util.normed_to_matrix(phys, 1)
+    P = eng.form_factor(feature, X).cpu().numpy()
+    nvx = cfg["parameters"]["electron"]["fe"]["nvx"]
+    vx, fe = orc.velocity_grid(nvx), orc.dlm_fe(2.0, nvx)
+    rng = cfg["other"]["lamrangE"] if feature == 0 else cfg["other"]["lamrangI"]
+    for b in range(B):
+        p = orc.lineout_params(phys, b, 1)
+        Po, _ = orc.form_factor(rng, cfg["other"]["npts"], 0.0, sa["sa"], 1, p, vx, fe)
+        err = np.max(np.abs(P[b] - Po) / np.abs(Po))
+        assert err < 1e-7, (b, err)  # IAW resonance amplifies rounding (|eps| << 1)
+
+
+def test_forward_reference_golden(torch_mod):
+    """The reference's own golden vector (tests/test_forward/test_1d.py:69,84: rtol 1e-4, atol 0),
+    computed by the HIP path: EPW only, DLM m=2.5 (through the Q6 round trip), 5120 -> 1024 samples."""
+    from tsadar_amd import ThomsonParams
+
+    cfg = decks.deck_1d()
+    eng = _engine(cfg, util.P9, activate=True)
+    tp = ThomsonParams(cfg["parameters"], num_params=1, batch=True, activate=True)
+    E, _ = eng.forward(tp.to_matrix(), np.array([1]), np.array([1]), np.array([0]), np.array([0]))
+    golden = np.load("tests/golden/ref_ThryE-1d.npy")
+    np.testing.assert_allclose(E.cpu().numpy(), golden, rtol=RTOL, atol=0)
+
+
+@pytest.mark.parametrize("ppp", [1, 2])
+def test_forward_matches_oracle(torch_mod, ppp):
+    """a1-a13: ThryE/ThryI of B random lineouts, EPW + IAW, with noise and amplitudes."""
+    cfg = decks.deck_fit(points_per_pixel=ppp)
+    B = 6
+    sa = util.sa_fit(B)
+    eng = _engine(cfg, sa)
+    normed = util.random_lineouts(cfg, B, seed=3)
+    rng = np.random.default_rng(5)
+    batch = dict(e_amps=rng.uniform(0.5, 2, B), i_amps=rng.uniform(0.5, 2, B),
+                 noise_e=0.01 * rng.random((B, 1024)), noise_i=0.01 * rng.random((B, 1024)),
+                 e_data=np.ones((B, 1024)), i_data=np.ones((B, 1024)))
+    Eo, Io, lE, lI = orc.ts_diag(cfg, sa, normed, batch)
+    E, I = eng.forward(util.normed_to_matrix(normed, 1), batch["e_amps"], batch["i_amps"], batch["noise_e"], batch["noise_i"])
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-9
+    assert util.rel_err(I.cpu().numpy(), Io) < 1e-8
+    np.testing.assert_allclose(eng.lamAxisE, lE[0], rtol=1e-14)
+    np.testing.assert_allclose(eng.lamAxisI, lI[0], rtol=1e-14)
+
+
+def test_forward_two_ions_gradient_points(torch_mod):
+    """a4-a10 with n_ion = 2 and num_grad_points = 3 (non-zero Te/ne gradients)."""
+    cfg = decks.deck_fit(n_ion=2)
+    g = cfg["parameters"]["general"]
+    g["Te_gradient"].update(val=6.0, num_grad_points=3)
+    g["ne_gradient"].update(val=9.0, num_grad_points=3)
+    B = 3
+    sa = util.sa_fit(B)
+    eng = _engine(cfg, sa)
+    normed = util.random_lineouts(cfg, B, seed=21)
+    batch = dict(e_amps=np.ones(B), i_amps=np.ones(B), noise_e=np.zeros((B, 1024)), noise_i=np.zeros((B, 1024)))
+    Eo, Io, _, _ = orc.ts_diag(cfg, sa, normed, batch)
+    E, I = eng.forward(util.normed_to_matrix(normed, 2), batch["e_amps"], batch["i_amps"])
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-9
+    assert util.rel_err(I.cpu().numpy(), Io) < 1e-8
+
+
+def test_forward_dlm_per_lineout(torch_mod):
+    """a2: DLM f_e built on the GPU from a per-lineout m (fe active), then the full chain."""
+    cfg = decks.deck_fit(active=("Te", "ne", "m", "amp1", "amp2", "lam"))
+    B = 4
+    sa = util.sa_fit(B)
+    eng = _engine(cfg, sa)
+    normed = util.random_lineouts(cfg, B, seed=8, ranges=dict(m=(2.0, 3.5)))
+    batch = dict(e_amps=np.ones(B), i_amps=np.ones(B), noise_e=np.zeros((B, 1024)), noise_i=np.zeros((B, 1024)))
+    Eo, Io, _, _ = orc.ts_diag(cfg, sa, normed, batch)
+    E, I = eng.forward(util.normed_to_matrix(normed, 1), batch["e_amps"], batch["i_amps"])
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-8
+    assert util.rel_err(I.cpu().numpy(), Io) < 1e-8
+
+
+def _loss_setup(cfg, B, seed=2):
+    sa = util.sa_fit(B)
+    batch = util.synthetic_batch(cfg, sa, B, seed=seed)
+    normed = util.random_lineouts(cfg, B, seed=seed + 50)
+    i_norm, e_norm = orc.loss_norms(cfg, batch)
+    return sa, batch, normed, i_norm, e_norm
+
+
+def test_loss_value_matches_oracle(torch_mod):
+    """a14: masked nanmean loss (iaw + blue + red) vs the oracle."""
+    cfg = decks.deck_fit()
+    B = 5
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B)
+    eng = _engine(cfg, sa)
+    lo, Eo, Io = orc.loss(cfg, sa, normed, batch, i_norm, e_norm)
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    terms, grad, E, I = eng.loss_grad(util.normed_to_matrix(normed, 1), batch, w, eng.slots.active.astype(np.uint8), want_spectra=True)
+    val = float(np.dot(terms.cpu().numpy(), w))
+    assert abs(val - lo) / abs(lo) < 1e-9, (val, lo)
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-9
+    assert util.rel_err(I.cpu().numpy(), Io) < 1e-8
+
+
+def _grad_case(torch_mod, active, names, B, seed, n_ion=1, tweak=None, tol=1e-7):
+    from oracle import tsadar_oracle_torch as ot
+
+    cfg = decks.deck_fit(active=active, n_ion=n_ion)
+    if tweak:
+        tweak(cfg)
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B, seed=seed)
+    eng = _engine(cfg, sa)
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    terms, grad, _, _ = eng.loss_grad(util.normed_to_matrix(normed, n_ion), batch, w, eng.slots.active.astype(np.uint8))
+    G = util.matrix_to_named(grad.cpu().numpy(), names)
+    val, ref, _, _ = ot.value_and_grad(cfg, sa, normed, batch, i_norm, e_norm, names)
+    assert abs(float(np.dot(terms.cpu().numpy(), w)) - val) < 1e-9 * abs(val)
+    scale = max(np.max(np.abs(v)) for v in ref.values())
+    for k in names:
+        err = np.max(np.abs(G[k] - ref[k])) / scale
+        assert err < tol, (k, G[k], ref[k])
+    # leaves that are not trainable get a zero gradient
+    g = grad.cpu().numpy()
+    for s in range(g.shape[1]):
+        if not eng.slots.active[s]:
+            assert np.all(g[:, s] == 0.0)
+
+
+def test_gradient_matches_autodiff_all_leaves(torch_mod):
+    """a15: the hand-written adjoint vs reverse-mode autodiff of the torch oracle twin (the role JAX
+    autodiff plays in the reference), every differentiable scalar leaf of a 1-ion deck, G = 1."""
+    names = ["Te", "ne", "Ti_1", "Z_1", "lam", "amp1", "amp2", "amp3", "ud", "Va", "Te_gradient", "ne_gradient"]
+
+    def tweak(cfg):
+        cfg["parameters"]["general"]["Te_gradient"]["val"] = 3.0
+        cfg["parameters"]["general"]["ne_gradient"]["val"] = 4.0
+
+    _grad_case(torch_mod, ("Te", "ne", "Ti", "Z", "lam", "amp1", "amp2", "amp3", "ud", "Va", "Te_gradient", "ne_gradient"),
+               names, B=2, seed=4, tweak=tweak)
+
+
+def test_gradient_baseline_active_set(torch_mod):
+    """a15 on the BASELINE active set {Te, ne, Ti, Va, lam, amp1}."""
+    _grad_case(torch_mod, ("Te", "ne", "Ti", "Va", "lam", "amp1"), ["Te", "ne", "Ti_1", "Va", "lam", "amp1"], B=3, seed=9)
+
+
+def test_gradient_two_ions_three_gradient_points(torch_mod):
+    """a15 with n_ion = 2 (fraction renormalisation, Zbar coupling) and num_grad_points = 3."""
+    def tweak(cfg):
+        g = cfg["parameters"]["general"]
+        g["Te_gradient"].update(val=5.0, num_grad_points=3)
+        g["ne_gradient"].update(val=8.0, num_grad_points=3)
+        cfg["parameters"]["ion-2"]["Z"]["active"] = True
+
+    names = ["Te", "ne", "Ti_1", "Ti_2", "Z_1", "Z_2", "lam", "Va", "Te_gradient", "ne_gradient", "amp1", "amp2", "amp3"]
+    _grad_case(torch_mod, ("Te", "ne", "Ti", "Z", "lam", "Va", "Te_gradient", "ne_gradient", "amp1", "amp2", "amp3"),
+               names, B=2, seed=13, n_ion=2, tweak=tweak)
+
+
+def test_gradient_tied_ion_temperature(torch_mod):
+    """ion-2.Ti.same = True ties Ti_2 to Ti_1 (ts_params.py:557-558): its adjoint flows to Ti_1."""
+    def tweak(cfg):
+        cfg["parameters"]["ion-2"]["Ti"]["same"] = True
+
+    _grad_case(torch_mod, ("Te", "ne", "Ti", "lam"), ["Te", "ne", "Ti_1", "Ti_2", "lam"], B=2, seed=17, n_ion=2, tweak=tweak)

@@ -1,0 +1,441 @@
+// tsff_device.h -- device-side building blocks of the form-factor kernels (gfx950 / CDNA4 only).
+//
+// Everything is float64.  The per-point physics follows FormFactor.__call__
+// (reference core/physics/form_factor.py:182-298, equations restated in DESIGN.md section 3);
+// the reverse sweep is a hand-written adjoint of exactly that arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tsff.h"
+
+namespace tsff {
+
+constexpr int kThreads = 256;    // 4 wavefronts of 64
+constexpr int kStrip = 4;        // consecutive wavelength samples owned by one thread
+constexpr int kNP_MAX = TSFF_NP(TSFF_MAX_ION);
+
+// physical constants (form_factor.py:123-125, 207-209)
+constexpr double kC = 2.99792458e10;
+constexpr double kMe = 510.9896 / (kC * kC);
+constexpr double kMp = kMe * 1836.1;
+constexpr double kRe = 2.8179e-13;
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kEsq = kMe * kC * kC * kRe;
+constexpr double kC0sq = 4.0 * kPi * kEsq / kMe;  // C0^2, omega_pe^2 = C0^2 * ne
+constexpr double kOmgLnum = 2.0 * kPi * 1e7 * kC;
+constexpr double kInvSqrt2Pi = 0.39894228040143267794;
+constexpr double kSqrt2 = 1.41421356237309504880;
+
+// xi2 grid of the Z' and W tables (form_factor.py:138): arange(-8.2, 8.2, 0.01)
+constexpr double kXi2_0 = -8.2;
+constexpr double kXi2_h = 0.01;
+constexpr double kXi2_ih = 100.0;
+constexpr int kNXi2 = TSFF_NXI2;
+constexpr int kNXi1 = TSFF_NXI1;
+
+// ------------------------------------------------------------------------------------------
+// wavefront / workgroup reductions (64-wide wavefronts, xor-shuffle butterflies)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sum over the workgroup; result valid in every thread.  scratch: >= 4 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+// max with lowest-index tie break; result valid in every thread.  scratch: >= 8 doubles.
+__device__ __forceinline__ void block_argmax(double& v, int& idx, double* scratch) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { scratch[w] = v; scratch[4 + w] = (double)idx; }
+  __syncthreads();
+  v = scratch[0]; idx = (int)scratch[4];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    double ov = scratch[k]; int oi = (int)scratch[4 + k];
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// table lookups (tables live in LDS)
+// ------------------------------------------------------------------------------------------
+struct Tables {
+  const double2* zp;   // [1640] (Re Z', Im Z') on xi2
+  const double* W;     // [1640] Re(chi_e) table on xi2
+  const double2* ht;   // [nvx]  (ln fe, node slope) on vx
+  double vx0, dv, idv, vxlast;
+  int nvx;
+};
+
+// jnp.interp(xi, xi2, Zp, left=xi**-2 / 0, right=xi**-2 / 0)  (form_factor.py:247-248)
+__device__ __forceinline__ void zprime_lookup(const double2* zp, double xi, double& zr, double& zi,
+                                              double& dzr, double& dzi) {
+  const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
+  double u = (xi - kXi2_0) * kXi2_ih;
+  int i = (int)u;
+  i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
+  const double t = (xi - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
+  const double2 a = zp[i], b = zp[i + 1];
+  const double dr = b.x - a.x, di = b.y - a.y;
+  if (xi < kXi2_0 || xi > xlast) {
+    const double i2 = 1.0 / (xi * xi);
+    zr = i2; zi = 0.0; dzr = -2.0 * i2 / xi; dzi = 0.0;
+  } else {
+    zr = a.x + t * dr; zi = a.y + t * di; dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
+  }
+}
+
+// jnp.interp(xie, xi2, W): clamps to the end values outside the table (form_factor.py:270)
+__device__ __forceinline__ void w_lookup(const double* W, double xe, double& w, double& dw) {
+  const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
+  double u = (xe - kXi2_0) * kXi2_ih;
+  int i = (int)u;
+  i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
+  const double t = (xe - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
+  const double a = W[i], b = W[i + 1];
+  if (xe < kXi2_0) { w = W[0]; dw = 0.0; }
+  else if (xe > xlast) { w = W[kNXi2 - 1]; dw = 0.0; }
+  else { w = a + t * (b - a); dw = (b - a) * kXi2_ih; }
+}
+
+// interpax.interp1d(x, vx, ln fe, method="cubic", extrap=[-50,-50])  (form_factor.py:256,263)
+// returns H = ln f(x) and dH/dx
+__device__ __forceinline__ void hermite_lookup(const Tables& T, double x, double& H, double& dH) {
+  double u = (x - T.vx0) * T.idv;
+  int i = (int)u;
+  i = i < 0 ? 0 : (i > T.nvx - 2 ? T.nvx - 2 : i);
+  const double t = (x - (T.vx0 + i * T.dv)) * T.idv;
+  const double2 a = T.ht[i], b = T.ht[i + 1];
+  const double f0 = a.x, f1 = b.x, m0 = a.y * T.dv, m1 = b.y * T.dv;
+  const double c2 = -3.0 * f0 + 3.0 * f1 - 2.0 * m0 - m1;
+  const double c3 = 2.0 * f0 - 2.0 * f1 + m0 + m1;
+  if (x < T.vx0 || x > T.vxlast) { H = -50.0; dH = 0.0; }
+  else {
+    H = f0 + t * (m0 + t * (c2 + t * c3));
+    dH = (m0 + t * (2.0 * c2 + 3.0 * t * c3)) * T.idv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// lineout-level scalars for one gradient point (form_factor.py:182-253)
+// ------------------------------------------------------------------------------------------
+template <int NI>
+struct Phys {  // physical parameters of one lineout (after ThomsonParams.__call__)
+  double Te, ne, m, lam, amp1, amp2, amp3, neg, teg, ud, Va;
+  double Ti[NI], Z[NI], A[NI], fr[NI];
+  double fsum;  // sum of the un-normalised fractions (ts_params.py:559-562)
+};
+
+template <int NI>
+struct LineS {
+  double wpe2, wL, kL, ivTe, a_e, pref, Ud, Vd;
+  double ixi[NI], a_i[NI], cs[NI];
+};
+
+// gradient-point factor: linspace(1 - v/200, 1 + v/200, G)[g] = 1 + v*cg   (form_factor.py:182-195)
+__device__ __forceinline__ double grad_coef(int g, int G) {
+  return G == 1 ? -1.0 / 200.0 : -1.0 / 200.0 + (double)g / (100.0 * (double)(G - 1));
+}
+
+template <int NI>
+__device__ __forceinline__ void make_lines(const Phys<NI>& p, double lam_shift, int g, int G, LineS<NI>& L) {
+  const double cg = grad_coef(g, G);
+  const double ne_g = 1.0e20 * p.ne * (1.0 + p.neg * cg);
+  const double Te_g = p.Te * (1.0 + p.teg * cg);
+  L.wL = kOmgLnum / (p.lam + lam_shift);
+  L.wpe2 = kC0sq * ne_g;
+  L.kL = sqrt(L.wL * L.wL - L.wpe2) / kC;
+  L.ivTe = 1.0 / sqrt(Te_g / kMe);
+  L.a_e = L.wpe2 * L.ivTe * L.ivTe;
+  L.pref = kRe * kRe * ne_g / (2.0 * kPi * kC);
+  L.Ud = p.ud * 1e6;
+  L.Vd = p.Va * 1e6;
+  double Zbar = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) Zbar += p.Z[s] * p.fr[s];
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    const double Ms = p.A[s] * kMp;
+    const double vTi = sqrt(p.Ti[s] / Ms);
+    L.ixi[s] = 1.0 / (kSqrt2 * vTi);
+    L.a_i[s] = kC0sq * kMe * p.Z[s] * p.Z[s] * p.fr[s] * ne_g / (Zbar * p.Ti[s]);
+    L.cs[s] = p.fr[s] * p.Z[s] * p.Z[s] / (Zbar * vTi);
+  }
+}
+
+// adjoint of make_lines: LB holds dL/d(LineS fields) summed over the points of gradient point g;
+// accumulates into pb[slot] (adjoint w.r.t. the PHYSICAL, renormalised parameters).
+template <int NI>
+__device__ __forceinline__ void make_lines_adjoint(const Phys<NI>& p, double lam_shift, int g, int G,
+                                                   const LineS<NI>& L, const LineS<NI>& LB, double* pb) {
+  const double cg = grad_coef(g, G);
+  const double gfn = 1.0 + p.neg * cg, gft = 1.0 + p.teg * cg;
+  const double ne_g = 1.0e20 * p.ne * gfn;
+  const double Te_g = p.Te * gft;
+  double wpe2b = LB.wpe2, wLb = LB.wL, ivTeb = LB.ivTe;
+  double ne_gb = LB.pref * (kRe * kRe / (2.0 * kPi * kC));
+  // a_e = wpe2 * ivTe^2
+  wpe2b += LB.a_e * L.ivTe * L.ivTe;
+  ivTeb += LB.a_e * 2.0 * L.wpe2 * L.ivTe;
+  // kL = sqrt(wL^2 - wpe2)/c
+  wLb += LB.kL * L.wL / (kC * kC * L.kL);
+  wpe2b += LB.kL * (-0.5 / (kC * kC * L.kL));
+  double Zbar = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) Zbar += p.Z[s] * p.fr[s];
+  double Zbarb = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    const double Ms = p.A[s] * kMp;
+    const double vTi = sqrt(p.Ti[s] / Ms);
+    const double Z2 = p.Z[s] * p.Z[s];
+    double Tib = 0.0, Zb = 0.0, frb = 0.0;
+    // a_i = C0^2 me Z^2 fr ne_g / (Zbar Ti)
+    const double ai_over_fr = kC0sq * kMe * Z2 * ne_g / (Zbar * p.Ti[s]);
+    Zb += LB.a_i[s] * 2.0 * L.a_i[s] / p.Z[s];
+    frb += LB.a_i[s] * ai_over_fr;
+    ne_gb += LB.a_i[s] * L.a_i[s] / ne_g;
+    Zbarb -= LB.a_i[s] * L.a_i[s] / Zbar;
+    Tib -= LB.a_i[s] * L.a_i[s] / p.Ti[s];
+    // ixi = 1/(sqrt2 vTi)
+    Tib += LB.ixi[s] * (-0.5 * L.ixi[s] / p.Ti[s]);
+    // cs = fr Z^2/(Zbar vTi)
+    Tib += LB.cs[s] * (-0.5 * L.cs[s] / p.Ti[s]);
+    Zb += LB.cs[s] * 2.0 * L.cs[s] / p.Z[s];
+    frb += LB.cs[s] * Z2 / (Zbar * vTi);
+    Zbarb -= LB.cs[s] * L.cs[s] / Zbar;
+    pb[TSFF_P_ION0 + 4 * s + TSFF_ION_TI] += Tib;
+    pb[TSFF_P_ION0 + 4 * s + TSFF_ION_Z] += Zb;
+    pb[TSFF_P_ION0 + 4 * s + TSFF_ION_FRACT] += frb;
+  }
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    pb[TSFF_P_ION0 + 4 * s + TSFF_ION_Z] += Zbarb * p.fr[s];
+    pb[TSFF_P_ION0 + 4 * s + TSFF_ION_FRACT] += Zbarb * p.Z[s];
+  }
+  // ivTe = sqrt(me/Te_g)
+  const double Te_gb = ivTeb * (-0.5 * L.ivTe / Te_g);
+  ne_gb += wpe2b * kC0sq;
+  const double lam0 = p.lam + lam_shift;
+  pb[TSFF_P_LAM] += wLb * (-L.wL / lam0);
+  pb[TSFF_P_NE] += ne_gb * 1.0e20 * gfn;
+  pb[TSFF_P_NE_GRADIENT] += ne_gb * 1.0e20 * p.ne * cg;
+  pb[TSFF_P_TE] += Te_gb * gft;
+  pb[TSFF_P_TE_GRADIENT] += Te_gb * p.Te * cg;
+  pb[TSFF_P_UD] += LB.Ud * 1e6;
+  pb[TSFF_P_VA] += LB.Vd * 1e6;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-point physics
+// ------------------------------------------------------------------------------------------
+struct Base {  // quantities needed at point j AND as the right neighbour of point j-1
+  double ks, k2, k, ik, wd, vph, xe, F, dH;
+};
+
+template <int NI>
+__device__ __forceinline__ void base_eval(double ws, double ks, double ct, const LineS<NI>& L, const Tables& T,
+                                          Base& b) {
+  b.ks = ks;                                               // form_factor.py:218 (angle independent, hoisted)
+  b.k2 = b.ks * b.ks + L.kL * L.kL - 2.0 * b.ks * L.kL * ct;  // :220
+  b.k = sqrt(b.k2);
+  b.ik = 1.0 / b.k;
+  b.wd = (ws - L.wL) - b.k * L.Vd;                         // :216, 222-223
+  b.vph = b.wd * b.ik;
+  b.xe = b.vph * L.ivTe - L.Ud * L.ivTe;                   // :253
+  double H;
+  hermite_lookup(T, b.xe, H, b.dH);
+  b.F = exp(H);                                            // :256
+}
+
+// P(lambda_j, theta_a) of one gradient point (form_factor.py:247-296)
+template <int NI>
+__device__ __forceinline__ double point_forward(double ws, const Base& b, const Base& bn, bool has_next,
+                                                const LineS<NI>& L, const Tables& T) {
+  const double ik2 = 1.0 / b.k2;
+  const double ike2 = L.a_e * ik2;
+  double cre = 0.0, cim = 0.0, gsum = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    const double xi = b.vph * L.ixi[s];                    // :243
+    double zr, zi, dzr, dzi;
+    zprime_lookup(T.zp, xi, zr, zi, dzr, dzi);
+    const double iki2 = L.a_i[s] * ik2;
+    cre -= 0.5 * iki2 * zr;                                // :249
+    cim -= 0.5 * iki2 * zi;
+    gsum += L.cs[s] * exp(-xi * xi) * kInvSqrt2Pi;         // :277-280
+  }
+  double Wl, dW;
+  w_lookup(T.W, b.xe, Wl, dW);
+  const double D = has_next ? (bn.F - b.F) / (bn.xe - b.xe) : 0.0;  // :258-259
+  const double cer = -ike2 * Wl;                           // :270-271
+  const double cei = kPi * ike2 * D;                       // :261
+  const double er = 1.0 + cer + cre, ei = cei + cim;       // :274
+  const double eps2 = er * er + ei * ei;
+  const double ce2 = cer * cer + cei * cei;
+  const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
+  const double S = (gsum * ce2 + ci2 * b.F * L.ivTe) * b.ik / eps2;  // :282-288
+  return S * (1.0 + 2.0 * b.wd / L.wL) * L.pref * ws * ws;           // :291-294
+}
+
+struct BaseAdj {  // adjoints flowing into base quantities of a point
+  double k2, ik, wd, vph, xe, F;
+};
+
+// reverse of point_forward: given Pbar, produce adjoints of this point's base quantities (ba),
+// of the right neighbour's (xe, F) (xen, Fn), and accumulate lineout-scalar adjoints into LB.
+template <int NI>
+__device__ __forceinline__ void point_reverse(double ws, const Base& b, const Base& bn, bool has_next,
+                                              const LineS<NI>& L, const Tables& T, double Pbar,
+                                              BaseAdj& ba, double& xen, double& Fn, LineS<NI>& LB) {
+  // ---- recompute forward ----
+  const double ik2 = 1.0 / b.k2;
+  const double ike2 = L.a_e * ik2;
+  double cre = 0.0, cim = 0.0, gsum = 0.0;
+  double xi[NI], zr[NI], zi[NI], dzr[NI], dzi[NI], iki2[NI], gs[NI];
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    xi[s] = b.vph * L.ixi[s];
+    zprime_lookup(T.zp, xi[s], zr[s], zi[s], dzr[s], dzi[s]);
+    iki2[s] = L.a_i[s] * ik2;
+    cre -= 0.5 * iki2[s] * zr[s];
+    cim -= 0.5 * iki2[s] * zi[s];
+    gs[s] = exp(-xi[s] * xi[s]) * kInvSqrt2Pi;
+    gsum += L.cs[s] * gs[s];
+  }
+  double Wl, dW;
+  w_lookup(T.W, b.xe, Wl, dW);
+  const double idx = has_next ? 1.0 / (bn.xe - b.xe) : 0.0;
+  const double D = has_next ? (bn.F - b.F) * idx : 0.0;
+  const double cer = -ike2 * Wl, cei = kPi * ike2 * D;
+  const double er = 1.0 + cer + cre, ei = cei + cim;
+  const double eps2 = er * er + ei * ei, ieps2 = 1.0 / eps2;
+  const double ce2 = cer * cer + cei * cei;
+  const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
+  const double N = gsum * ce2 + ci2 * b.F * L.ivTe;
+  const double S = N * b.ik * ieps2;
+  const double dop = 1.0 + 2.0 * b.wd / L.wL;
+  const double Q = L.pref * ws * ws;
+  // ---- reverse ----
+  const double Sb = Pbar * dop * Q;
+  ba.wd = Pbar * S * Q * 2.0 / L.wL;
+  LB.wL += Pbar * S * Q * (-2.0 * b.wd / (L.wL * L.wL));
+  LB.pref += Pbar * S * dop * ws * ws;
+  const double Nb = Sb * b.ik * ieps2;
+  ba.ik = Sb * N * ieps2;
+  const double eps2b = -Sb * N * b.ik * ieps2 * ieps2;
+  const double ci2b = Nb * b.F * L.ivTe;
+  ba.F = Nb * ci2 * L.ivTe;
+  LB.ivTe += Nb * ci2 * b.F;
+  const double ce2b = Nb * gsum;
+  const double erb = eps2b * 2.0 * er, eib = eps2b * 2.0 * ei;
+  const double cerb = erb + ce2b * 2.0 * cer, ceib = eib + ce2b * 2.0 * cei;
+  const double creb = erb + ci2b * 2.0 * (1.0 + cre), cimb = eib + ci2b * 2.0 * cim;
+  double ike2b = -cerb * Wl + ceib * kPi * D;
+  ba.xe = -cerb * ike2 * dW;
+  const double Db = ceib * kPi * ike2;
+  // D = (Fn - F) * idx
+  Fn = Db * idx;
+  ba.F -= Db * idx;
+  xen = -Db * D * idx;
+  ba.xe += Db * D * idx;
+  double k2b = 0.0, vphb = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    LB.cs[s] += Nb * ce2 * gs[s];
+    double xib = Nb * ce2 * L.cs[s] * gs[s] * (-2.0 * xi[s]);
+    const double iki2b = -0.5 * (creb * zr[s] + cimb * zi[s]);
+    xib += -0.5 * iki2[s] * (creb * dzr[s] + cimb * dzi[s]);
+    LB.a_i[s] += iki2b * ik2;
+    k2b -= iki2b * iki2[s] * ik2;
+    vphb += xib * L.ixi[s];
+    LB.ixi[s] += xib * b.vph;
+  }
+  LB.a_e += ike2b * ik2;
+  k2b -= ike2b * ike2 * ik2;
+  ba.k2 = k2b;
+  ba.vph = vphb;
+}
+
+// reverse of base_eval
+template <int NI>
+__device__ __forceinline__ void base_reverse(double ct, const Base& b, const LineS<NI>& L, const BaseAdj& ba,
+                                             LineS<NI>& LB) {
+  const double xeb = ba.xe + ba.F * b.F * b.dH;
+  // xe = (vph - Ud) * ivTe
+  const double vphb = ba.vph + xeb * L.ivTe;
+  LB.Ud -= xeb * L.ivTe;
+  LB.ivTe += xeb * (b.vph - L.Ud);
+  // vph = wd * ik
+  const double wdb = ba.wd + vphb * b.ik;
+  const double ikb = ba.ik + vphb * b.wd;
+  // wd = ws - wL - k Vd
+  LB.wL -= wdb;
+  LB.Vd -= wdb * b.k;
+  double kb = -wdb * L.Vd;
+  kb -= ikb * b.ik * b.ik;
+  const double k2b = ba.k2 + kb * 0.5 * b.ik;
+  const double ksb = k2b * 2.0 * (b.ks - L.kL * ct);
+  LB.kL += k2b * 2.0 * (L.kL - b.ks * ct);
+  LB.wpe2 += ksb * (-0.5 / (kC * kC * b.ks));
+}
+
+template <int NI>
+__device__ __forceinline__ void zero_lines(LineS<NI>& L) {
+  L.wpe2 = L.wL = L.kL = L.ivTe = L.a_e = L.pref = L.Ud = L.Vd = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) L.ixi[s] = L.a_i[s] = L.cs[s] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// parameter transform  (ts_params.py:329-350, 543-603)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+template <int NI>
+__device__ __forceinline__ void load_phys(const double* __restrict__ x, const double* __restrict__ scale,
+                                          const double* __restrict__ shift, const uint8_t* __restrict__ sig,
+                                          const uint8_t* ti_same, bool activate, Phys<NI>& p) {
+  auto tr = [&](int s) {
+    const double v = x[s];
+    if (!activate) return v;
+    return (sig[s] ? sigmoid(v) : v) * scale[s] + shift[s];
+  };
+  p.Te = tr(TSFF_P_TE); p.ne = tr(TSFF_P_NE); p.m = tr(TSFF_P_M); p.lam = tr(TSFF_P_LAM);
+  p.amp1 = tr(TSFF_P_AMP1); p.amp2 = tr(TSFF_P_AMP2); p.amp3 = tr(TSFF_P_AMP3);
+  p.neg = tr(TSFF_P_NE_GRADIENT); p.teg = tr(TSFF_P_TE_GRADIENT);
+  p.ud = tr(TSFF_P_UD); p.Va = tr(TSFF_P_VA);
+  double fsum = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    const int o = TSFF_P_ION0 + 4 * s;
+    p.Ti[s] = tr(o + TSFF_ION_TI); p.Z[s] = tr(o + TSFF_ION_Z);
+    p.A[s] = tr(o + TSFF_ION_A); p.fr[s] = tr(o + TSFF_ION_FRACT);
+    if (s > 0 && ti_same[s]) p.Ti[s] = p.Ti[0];
+    fsum += p.fr[s];
+  }
+  p.fsum = fsum;
+  if (activate) {
+#pragma unroll
+    for (int s = 0; s < NI; ++s) p.fr[s] /= fsum;
+  }
+}
+
+}  // namespace tsff

@@ -1,0 +1,556 @@
+// tsff_kernels.hip -- HIP kernels of the Thomson-scattering form-factor engine (gfx950 only).
+//
+// Kernel map (reference rows are those of SURVEY.md section 8a; DESIGN.md section 4 has the details)
+//   k_fe_prepare   a2, a6(table part), a8 : f_e -> ln f_e Hermite table, ratmod, ratdf, W[1640] (ratintn)
+//   k_spectrum     a1, a4-a15            : one workgroup per (lineout, feature); forward sweep over
+//                                          (lambda x theta), IRF convolution, binning, normalisation,
+//                                          loss partials and -- MODE 1 -- the hand-written adjoint
+//   k_finalize     a1 (chain rule), a15  : per-lineout gradient w.r.t. the normalised leaves
+//   k_loss_reduce  a14                   : deterministic reduction of the masked loss sums
+//   k_form_factor  a4-a10                : raw FormFactor.__call__ output (known-answer tests)
+#include "tsff_device.h"
+
+namespace tsff {
+
+// static, per-handle device configuration (passed by value)
+struct KStatic {
+  int npts, ppp, n_angles, G, nvx, NP;
+  int shared_fe;  // 1: every lineout uses table slot 0
+  int loss_method;
+  int load[2];
+  double lam_shift[2];
+  const double* omgs[2];     // [npts] scattered-frequency axis (form_factor.py:134)
+  const double* lam_bin[2];  // [1024] binned wavelength axis in nm (irf.py:75,125)
+  const double* filt;        // [npts] EPW multiplier (iawfilter) or nullptr
+  const double* cos_sa;      // [n_angles]
+  const double* w_sa;        // [n_angles]
+  const double2* zp;         // [1640]
+  const double* xi1;         // [1024]
+  const double* xi2;         // [1640]
+  const double* taps[2];
+  int ntaps[2];
+  int dmin[2];
+  const uint8_t* mask[2];    // [1024]
+  const double* p_scale;
+  const double* p_shift;
+  const uint8_t* p_sig;
+  const double* dlm_table;   // [nvx][31]
+  uint8_t ti_same[TSFF_MAX_ION];
+  double vx0, dv;
+};
+
+// per-call pointers (device)
+struct KCall {
+  const double* params;  // [B][NP]
+  const double2* ht;     // [slots][nvx]
+  const double* W;       // [slots][1640]
+  const double* amps[2];
+  const double* noise[2];
+  const double* data[2];
+  double* thry[2];
+  double* sqdev[2];
+  double* gpart;         // [B][2][NP]
+  double* lpart;         // [B][3]
+  double wts[3];
+  int B;
+};
+
+// ------------------------------------------------------------------------------------------
+// k_fe_prepare: distribution function -> Hermite table of ln fe and the Re(chi_e) table W
+// grid (slots, qsplit), 256 threads.   reference: form_factor.py:263-268, ratintn.py:4-52,
+// base.py:277-294 (DLM), interpax _approx_df (node slopes)
+// ------------------------------------------------------------------------------------------
+template <int NI>
+__global__ __launch_bounds__(kThreads) void k_fe_prepare(KStatic S, const double* __restrict__ fe_in, int fe_mode,
+                                                         const double* __restrict__ params, double2* __restrict__ ht_out,
+                                                         double* __restrict__ W_out, double* __restrict__ fe_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* lnfe = reinterpret_cast<double*>(smem);  // [nvx]
+  double* slope = lnfe + S.nvx;                    // [nvx]
+  double* ratmod = slope + S.nvx;                  // [1024]
+  double* ratdf = ratmod + kNXi1;                  // [1024]
+  double* xi1 = ratdf + kNXi1;                     // [1024]
+  double* red = xi1 + kNXi1;                       // [8]
+  double2* ht = reinterpret_cast<double2*>(red + 8);  // [nvx]
+
+  const int slot = blockIdx.x, tid = threadIdx.x;
+  const int nvx = S.nvx;
+
+  // ---- fe on the vx grid ----
+  if (fe_mode == TSFF_FE_DLM) {
+    // DLM1V.__call__ (base.py:277-294): interp in m over m_ax = linspace(2,5,31), then /sum/dv
+    Phys<NI> p;
+    load_phys<NI>(params + (size_t)slot * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+    const double m = p.m;
+    double u = (m - 2.0) * 10.0;
+    int k = (int)u;
+    k = k < 0 ? 0 : (k > TSFF_DLM_NM - 2 ? TSFF_DLM_NM - 2 : k);
+    double t = (m - (2.0 + 0.1 * k)) * 10.0;
+    t = m < 2.0 ? 0.0 : (m > 5.0 ? 1.0 : t);
+    double part = 0.0;
+    for (int i = tid; i < nvx; i += kThreads) {
+      const double a = S.dlm_table[i * TSFF_DLM_NM + k], b = S.dlm_table[i * TSFF_DLM_NM + k + 1];
+      const double f = a + t * (b - a);
+      lnfe[i] = f;
+      part += f;
+    }
+    const double tot = block_sum(part, red);
+    for (int i = tid; i < nvx; i += kThreads) {
+      const double f = lnfe[i] / tot / S.dv;
+      if (fe_out && blockIdx.y == 0) fe_out[(size_t)slot * nvx + i] = f;
+      lnfe[i] = log(f);
+    }
+  } else {
+    for (int i = tid; i < nvx; i += kThreads) lnfe[i] = log(fe_in[(size_t)slot * nvx + i]);
+  }
+  for (int i = tid; i < kNXi1; i += kThreads) xi1[i] = S.xi1[i];
+  __syncthreads();
+  // ---- node slopes: mean of adjacent secants, one-sided at the ends ----
+  for (int i = tid; i < nvx; i += kThreads) {
+    const double dl = i > 0 ? (lnfe[i] - lnfe[i - 1]) / S.dv : 0.0;
+    const double dr = i < nvx - 1 ? (lnfe[i + 1] - lnfe[i]) / S.dv : 0.0;
+    const double s = i == 0 ? dr : (i == nvx - 1 ? dl : 0.5 * (dl + dr));
+    slope[i] = s;
+    ht[i] = make_double2(lnfe[i], s);
+    if (blockIdx.y == 0) ht_out[(size_t)slot * nvx + i] = make_double2(lnfe[i], s);
+  }
+  __syncthreads();
+  Tables T;
+  T.zp = nullptr; T.W = nullptr; T.ht = ht; T.nvx = nvx;
+  T.vx0 = S.vx0; T.dv = S.dv; T.idv = 1.0 / S.dv; T.vxlast = S.vx0 + (nvx - 1) * S.dv;
+  // ---- ratmod = exp(H(xi1)) (form_factor.py:263) ----
+  for (int i = tid; i < kNXi1; i += kThreads) {
+    double H, dH;
+    hermite_lookup(T, xi1[i], H, dH);
+    ratmod[i] = exp(H);
+  }
+  __syncthreads();
+  // ---- ratdf = gradient(ratmod, dxi1) (form_factor.py:264) ----
+  const double h1 = xi1[1] - xi1[0];
+  for (int i = tid; i < kNXi1; i += kThreads) {
+    double g;
+    if (i == 0) g = (ratmod[1] - ratmod[0]) / h1;
+    else if (i == kNXi1 - 1) g = (ratmod[kNXi1 - 1] - ratmod[kNXi1 - 2]) / h1;
+    else g = (ratmod[i + 1] - ratmod[i - 1]) / (2.0 * h1);
+    ratdf[i] = g;
+  }
+  __syncthreads();
+  // ---- W[q] = ratintn(ratdf, xi1 - xi2[q], xi1): one wavefront per q, lanes stride the 1022
+  //      intervals, xor-shuffle reduction (ratintn.py:21, 41-52; the last interval is dropped) ----
+  const int lane = tid & 63, wave = tid >> 6;
+  const int qper = (kNXi2 + gridDim.y - 1) / gridDim.y;
+  const int q0 = blockIdx.y * qper, q1 = min(kNXi2, q0 + qper);
+  for (int q = q0 + wave; q < q1; q += kThreads / 64) {
+    const double x2 = S.xi2[q];
+    double acc = 0.0;
+    for (int i = lane; i < kNXi1 - 2; i += 64) {
+      const double f0 = ratdf[i], f1 = ratdf[i + 1];
+      const double g0 = xi1[i] - x2, g1 = xi1[i + 1] - x2;
+      const double fdif = f1 - f0, gdif = g1 - g0;
+      const double fav = 0.5 * (f1 + f0), gav = 0.5 * (g1 + g0);
+      const double tmp = fav * gdif - gav * fdif;
+      double r;
+      if (fabs(gdif) < 1.0e-4 * fabs(gav)) r = fav / gav + tmp * gdif / (12.0 * gav * gav * gav);
+      else r = fdif / gdif + tmp * log(fabs((gav + 0.5 * gdif) / (gav - 0.5 * gdif))) / (gdif * gdif);
+      acc += r * (xi1[i + 1] - xi1[i]);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) W_out[(size_t)slot * kNXi2 + q] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// shared helpers of the spectrum kernels
+// ------------------------------------------------------------------------------------------
+struct Smem {
+  double2* zp;   // [1640]
+  double2* ht;   // [nvx]
+  double* W;     // [1640]
+  double* x;     // [npts]   model spectrum, later its adjoint
+  double* yb;    // [1024]   adjoint of the binned spectrum (MODE 1)
+  double* taps;  // [ntaps]
+  double* cosa;  // [n_angles]
+  double* wsa;   // [n_angles]
+  double* red;   // [4 * kNP_MAX + 16]
+};
+
+__device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int ntaps) {
+  Smem m;
+  m.zp = reinterpret_cast<double2*>(smem);
+  m.ht = m.zp + kNXi2;
+  m.W = reinterpret_cast<double*>(m.ht + S.nvx);
+  m.x = m.W + kNXi2;
+  m.yb = m.x + S.npts;
+  m.taps = m.yb + TSFF_NBINS;
+  m.cosa = m.taps + ntaps;
+  m.wsa = m.cosa + S.n_angles;
+  m.red = m.wsa + S.n_angles;
+  return m;
+}
+
+__device__ __forceinline__ void load_tables(const Smem& m, const KStatic& S, const KCall& K, int slot, int f,
+                                            Tables& T) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kNXi2; i += kThreads) {
+    m.zp[i] = S.zp[i];
+    m.W[i] = K.W[(size_t)slot * kNXi2 + i];
+  }
+  for (int i = tid; i < S.nvx; i += kThreads) m.ht[i] = K.ht[(size_t)slot * S.nvx + i];
+  if (f >= 0)
+    for (int i = tid; i < S.ntaps[f]; i += kThreads) m.taps[i] = S.taps[f][i];
+  for (int i = tid; i < S.n_angles; i += kThreads) { m.cosa[i] = S.cos_sa[i]; m.wsa[i] = S.w_sa[i]; }
+  T.zp = m.zp; T.W = m.W; T.ht = m.ht; T.nvx = S.nvx;
+  T.vx0 = S.vx0; T.dv = S.dv; T.idv = 1.0 / S.dv; T.vxlast = S.vx0 + (S.nvx - 1) * S.dv;
+}
+
+// loss functional e(d, t) and de/dt (loss_function.py:386-418); the 1/uncert of l1/l2 is folded
+// into the weights by the host (constant denominators) or applied here (theory denominator).
+__device__ __forceinline__ void loss_point(int method, double d, double t, double& e, double& det) {
+  const double r = d - t;
+  if (method == TSFF_LOSS_L2) { e = r * r; det = -2.0 * r; }
+  else if (method == TSFF_LOSS_L1) { e = fabs(r); det = r > 0.0 ? -1.0 : (r < 0.0 ? 1.0 : 0.0); }
+  else if (method == TSFF_LOSS_LOGCOSH) { e = log(cosh(r)); det = -tanh(r); }
+  else { e = t - d * log(t); det = 1.0 - d / t; }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_spectrum: one workgroup per (lineout b, feature f).
+//   MODE 0: ThryE/ThryI                       (ThomsonScatteringDiagnostic.__call__)
+//   MODE 1: + masked loss sums + adjoint       (LossFunction.vg_loss)
+//   MODE 2: + per-lineout sums, theory denominator, sqdev arrays (LossFunction.array_loss)
+// ------------------------------------------------------------------------------------------
+template <int NI, int MODE>
+__global__ __launch_bounds__(kThreads) void k_spectrum(KStatic S, KCall K) {
+  const int b = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  if (!S.load[f]) return;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int ntmax = S.ntaps[0] > S.ntaps[1] ? S.ntaps[0] : S.ntaps[1];
+  const Smem m = carve(smem, S, ntmax);
+  Tables T;
+  load_tables(m, S, K, S.shared_fe ? 0 : b, f, T);
+
+  Phys<NI> p;
+  load_phys<NI>(K.params + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+  const double lam_shift = S.lam_shift[f];
+  const double* __restrict__ omgs = S.omgs[f];
+  const int npts = S.npts, ppp = S.ppp, G = S.G, NA = S.n_angles;
+  const double invG = 1.0 / (double)G;
+  __syncthreads();
+
+  // ================= forward sweep over (lambda strip, gradient point, angle) =================
+  for (int c = 0; c < ppp; ++c) {
+    const int j0 = kStrip * (tid + kThreads * c);
+    double ws[kStrip + 1];
+#pragma unroll
+    for (int q = 0; q <= kStrip; ++q) ws[q] = omgs[min(j0 + q, npts - 1)];
+    double xacc[kStrip];
+#pragma unroll
+    for (int q = 0; q < kStrip; ++q) xacc[q] = 0.0;
+    for (int g = 0; g < G; ++g) {
+      LineS<NI> L;
+      make_lines<NI>(p, lam_shift, g, G, L);
+      double ksv[kStrip + 1];
+#pragma unroll
+      for (int q = 0; q <= kStrip; ++q) ksv[q] = sqrt(ws[q] * ws[q] - L.wpe2) / kC;
+      for (int a = 0; a < NA; ++a) {
+        const double ct = m.cosa[a], wa = m.wsa[a];
+        Base b0;
+        base_eval<NI>(ws[0], ksv[0], ct, L, T, b0);
+#pragma unroll
+        for (int q = 0; q < kStrip; ++q) {
+          const bool has_next = (j0 + q + 1) < npts;
+          Base b1;
+          base_eval<NI>(ws[q + 1], ksv[q + 1], ct, L, T, b1);
+          xacc[q] += wa * point_forward<NI>(ws[q], b0, b1, has_next, L, T);
+          b0 = b1;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kStrip; ++q) {
+      const int j = j0 + q;
+      double v = xacc[q] * invG;
+      if (f == TSFF_FEATURE_ELE && S.filt) v *= S.filt[j];
+      m.x[j] = v;
+    }
+  }
+  __syncthreads();
+
+  // ================= IRF convolution ("same"), bin average, normalisation =================
+  const int nt = S.ntaps[f], dmin = S.dmin[f], dmax = dmin + nt - 1;
+  const double invp = 1.0 / (double)ppp;
+  double ybin[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pb = tid + kThreads * r;
+    double acc = 0.0;
+    for (int jj = 0; jj < ppp; ++jj) {
+      const int j = pb * ppp + jj;
+      const int ilo = max(0, j - dmax), ihi = min(npts - 1, j - dmin);
+      double s = 0.0;
+      for (int i = ilo; i <= ihi; ++i) s += m.taps[j - i - dmin] * m.x[i];
+      acc += s;
+    }
+    ybin[r] = acc * invp;
+  }
+  double M = ybin[0];
+  int pstar = tid;
+#pragma unroll
+  for (int r = 1; r < 4; ++r)
+    if (ybin[r] > M) { M = ybin[r]; pstar = tid + kThreads * r; }
+  block_argmax(M, pstar, m.red);
+  const double invM = 1.0 / M;
+  const double amps = K.amps[f][b];
+  const double* __restrict__ lamb = S.lam_bin[f];
+  double Tb[4];   // dLoss/dT (MODE 1)
+  double Ap[4];   // amplitude factor of bin p
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pb = tid + kThreads * r;
+    double A;
+    if (f == TSFF_FEATURE_ELE) A = amps * (lamb[pb] < p.lam ? p.amp1 : p.amp2);  // irf.py:126-130
+    else A = amps * p.amp3;                                                      // irf.py:76
+    Ap[r] = A;
+    double t = A * ybin[r] * invM;
+    if (K.noise[f]) t += K.noise[f][(size_t)b * TSFF_NBINS + pb];             // thomson_diagnostic.py:139-140
+    if (K.thry[f]) K.thry[f][(size_t)b * TSFF_NBINS + pb] = t;
+    Tb[r] = 0.0;
+    if (MODE >= 1) {
+      const double d = K.data[f][(size_t)b * TSFF_NBINS + pb];
+      const uint8_t mk = S.mask[f][pb];
+      double e, det;
+      loss_point(S.loss_method, d, t, e, det);
+      if (MODE == 2) {
+        if (S.loss_method == TSFF_LOSS_L2 || S.loss_method == TSFF_LOSS_L1) e /= t;  // loss_function.py:320-321
+        double sq = 0.0;
+        if (mk & 1) { s0 += e; sq += e; }
+        if (mk & 2) { s1 += e; sq += e; }
+        if (K.sqdev[f]) K.sqdev[f][(size_t)b * TSFF_NBINS + pb] = sq;
+      } else {
+        double w = 0.0;
+        if (mk & 1) { s0 += e; w += (f == TSFF_FEATURE_ELE ? K.wts[1] : K.wts[0]); }
+        if (mk & 2) { s1 += e; w += K.wts[2]; }
+        Tb[r] = det * w;
+      }
+    }
+  }
+  if (MODE == 0) return;
+  s0 = block_sum(s0, m.red);
+  s1 = block_sum(s1, m.red);
+  if (tid == 0) {
+    if (f == TSFF_FEATURE_ELE) { K.lpart[(size_t)b * 3 + 1] = s0; K.lpart[(size_t)b * 3 + 2] = s1; }
+    else K.lpart[(size_t)b * 3 + 0] = s0;
+  }
+  if (MODE == 2) return;
+
+  // ================= adjoint of normalisation + binning =================
+  // T_p = A_p ybin_p / M (+ noise), M = max_p ybin_p attained at pstar
+  double sn = 0.0, a1b = 0.0, a2b = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pb = tid + kThreads * r;
+    const double u = Tb[r] * ybin[r] * invM;  // dL/dA_p
+    sn += u * Ap[r];
+    if (f == TSFF_FEATURE_ELE) { if (lamb[pb] < p.lam) a1b += u * amps; else a2b += u * amps; }
+    else a1b += u * amps;
+  }
+  sn = block_sum(sn, m.red);
+  a1b = block_sum(a1b, m.red);
+  a2b = block_sum(a2b, m.red);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pb = tid + kThreads * r;
+    double yb = Tb[r] * Ap[r] * invM;
+    if (pb == pstar) yb -= sn * invM;
+    m.yb[pb] = yb * invp;
+  }
+  __syncthreads();
+  // ================= adjoint of the convolution: xbar_i = filt_i * sum_j ybar_j g[j-i] =================
+  for (int i = tid; i < npts; i += kThreads) {
+    const int jlo = max(0, i + dmin), jhi = min(npts - 1, i + dmax);
+    double s = 0.0;
+    for (int j = jlo; j <= jhi; ++j) s += m.taps[j - i - dmin] * m.yb[j / ppp];
+    if (f == TSFF_FEATURE_ELE && S.filt) s *= S.filt[i];
+    m.x[i] = s * invG;
+  }
+  __syncthreads();
+
+  // ================= reverse sweep: recompute each point, accumulate parameter adjoints =================
+  constexpr int NPk = TSFF_NP(NI);
+  double pbar[NPk];
+#pragma unroll
+  for (int s = 0; s < NPk; ++s) pbar[s] = 0.0;
+  for (int g = 0; g < G; ++g) {
+    LineS<NI> L, LB;
+    make_lines<NI>(p, lam_shift, g, G, L);
+    zero_lines<NI>(LB);
+    for (int c = 0; c < ppp; ++c) {
+      const int j0 = kStrip * (tid + kThreads * c);
+      double ws[kStrip + 1], ksv[kStrip + 1], xb[kStrip];
+#pragma unroll
+      for (int q = 0; q <= kStrip; ++q) {
+        ws[q] = omgs[min(j0 + q, npts - 1)];
+        ksv[q] = sqrt(ws[q] * ws[q] - L.wpe2) / kC;
+      }
+#pragma unroll
+      for (int q = 0; q < kStrip; ++q) xb[q] = m.x[j0 + q];
+      for (int a = 0; a < NA; ++a) {
+        const double ct = m.cosa[a], wa = m.wsa[a];
+        Base b0;
+        base_eval<NI>(ws[0], ksv[0], ct, L, T, b0);
+        double cxe = 0.0, cF = 0.0;
+        bool last_has_next = false;
+#pragma unroll
+        for (int q = 0; q < kStrip; ++q) {
+          const bool has_next = (j0 + q + 1) < npts;
+          Base b1;
+          base_eval<NI>(ws[q + 1], ksv[q + 1], ct, L, T, b1);
+          BaseAdj ba;
+          double xen, Fn;
+          point_reverse<NI>(ws[q], b0, b1, has_next, L, T, xb[q] * wa, ba, xen, Fn, LB);
+          ba.xe += cxe; ba.F += cF;
+          base_reverse<NI>(ct, b0, L, ba, LB);
+          cxe = xen; cF = Fn;
+          b0 = b1;
+          last_has_next = has_next;
+        }
+        if (last_has_next) {  // the strip's right neighbour receives the D-coupling of the last point
+          BaseAdj ba;
+          ba.k2 = ba.ik = ba.wd = ba.vph = 0.0; ba.xe = cxe; ba.F = cF;
+          base_reverse<NI>(ct, b0, L, ba, LB);
+        }
+      }
+    }
+    make_lines_adjoint<NI>(p, lam_shift, g, G, L, LB, pbar);
+  }
+  // amplitudes (irf.py:76,126-130)
+  if (f == TSFF_FEATURE_ELE) {
+    if (tid == 0) { pbar[TSFF_P_AMP1] += a1b; pbar[TSFF_P_AMP2] += a2b; }
+  } else {
+    if (tid == 0) pbar[TSFF_P_AMP3] += a1b;
+  }
+  // workgroup reduction of the parameter adjoints -> gpart[b][f][:]
+  const int lane = tid & 63, wave = tid >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NPk; ++s) {
+    const double v = wave_sum(pbar[s]);
+    if (lane == 0) m.red[wave * NPk + s] = v;
+  }
+  __syncthreads();
+  if (tid < NPk)
+    K.gpart[((size_t)b * 2 + f) * S.NP + tid] =
+        (m.red[tid] + m.red[NPk + tid]) + (m.red[2 * NPk + tid] + m.red[3 * NPk + tid]);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finalize: gradient w.r.t. the normalised leaves.  One thread per lineout.
+// chain: feature sum -> Ti tying -> fraction renormalisation -> activation * scale
+// (ts_params.py:329-350, 543-563)
+// ------------------------------------------------------------------------------------------
+template <int NI>
+__global__ void k_finalize(KStatic S, const double* __restrict__ params, const double* __restrict__ gpart,
+                           const uint8_t* __restrict__ gmask, double* __restrict__ grad, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  constexpr int NPk = TSFF_NP(NI);
+  double g[NPk];
+#pragma unroll
+  for (int s = 0; s < NPk; ++s) {
+    double v = 0.0;
+    if (S.load[0]) v += gpart[((size_t)b * 2 + 0) * NPk + s];
+    if (S.load[1]) v += gpart[((size_t)b * 2 + 1) * NPk + s];
+    g[s] = v;
+  }
+  const double* x = params + (size_t)b * NPk;
+  Phys<NI> p;
+  load_phys<NI>(x, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+  // Ti tying
+#pragma unroll
+  for (int s = 1; s < NI; ++s)
+    if (S.ti_same[s]) {
+      g[TSFF_P_ION0 + TSFF_ION_TI] += g[TSFF_P_ION0 + 4 * s + TSFF_ION_TI];
+      g[TSFF_P_ION0 + 4 * s + TSFF_ION_TI] = 0.0;
+    }
+  // fract_s = f_s / sum(f)
+  double dot = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) dot += g[TSFF_P_ION0 + 4 * s + TSFF_ION_FRACT] * p.fr[s];
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    const int o = TSFF_P_ION0 + 4 * s + TSFF_ION_FRACT;
+    g[o] = (g[o] - dot) / p.fsum;
+    g[TSFF_P_ION0 + 4 * s + TSFF_ION_A] = 0.0;
+  }
+  g[TSFF_P_M] = 0.0;
+#pragma unroll
+  for (int s = 0; s < NPk; ++s) {
+    double v = g[s] * S.p_scale[s];
+    if (S.p_sig[s]) { const double sg = sigmoid(x[s]); v *= sg * (1.0 - sg); }
+    grad[(size_t)b * NPk + s] = gmask[s] ? v : 0.0;
+  }
+}
+
+// deterministic reduction of lpart[B][3] -> out[3]; one workgroup, fixed order
+__global__ __launch_bounds__(kThreads) void k_loss_reduce(const double* __restrict__ lpart, int B, double* __restrict__ out) {
+  __shared__ double red[8];
+  double a[3] = {0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < B; b += kThreads) {
+    a[0] += lpart[(size_t)b * 3 + 0]; a[1] += lpart[(size_t)b * 3 + 1]; a[2] += lpart[(size_t)b * 3 + 2];
+  }
+  for (int k = 0; k < 3; ++k) {
+    const double v = block_sum(a[k], red);
+    if (threadIdx.x == 0) out[k] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_form_factor: raw FormFactor.__call__ (form_factor.py:163-298) -> P[b][g][j][a], physical
+// parameters in, no instrument chain.  One workgroup per lineout; any npts.
+// ------------------------------------------------------------------------------------------
+template <int NI>
+__global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, int f, const double* __restrict__ omgs,
+                                                          int npts, double* __restrict__ P) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const Smem m = carve(smem, S, 0);
+  Tables T;
+  load_tables(m, S, K, S.shared_fe ? 0 : b, -1, T);
+  Phys<NI> p;
+  load_phys<NI>(K.params + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, false, p);
+  __syncthreads();
+  const int G = S.G, NA = S.n_angles;
+  const int nstrips = (npts + kStrip - 1) / kStrip;
+  for (int st = tid; st < nstrips; st += kThreads) {
+    const int j0 = st * kStrip;
+    double ws[kStrip + 1];
+#pragma unroll
+    for (int q = 0; q <= kStrip; ++q) ws[q] = omgs[min(j0 + q, npts - 1)];
+    for (int g = 0; g < G; ++g) {
+      LineS<NI> L;
+      make_lines<NI>(p, S.lam_shift[f], g, G, L);
+      double ksv[kStrip + 1];
+#pragma unroll
+      for (int q = 0; q <= kStrip; ++q) ksv[q] = sqrt(ws[q] * ws[q] - L.wpe2) / kC;
+      for (int a = 0; a < NA; ++a) {
+        const double ct = m.cosa[a];
+        Base b0;
+        base_eval<NI>(ws[0], ksv[0], ct, L, T, b0);
+#pragma unroll
+        for (int q = 0; q < kStrip; ++q) {
+          const int j = j0 + q;
+          const bool has_next = (j + 1) < npts;
+          Base b1;
+          base_eval<NI>(ws[q + 1], ksv[q + 1], ct, L, T, b1);
+          if (j < npts) P[(((size_t)b * G + g) * npts + j) * NA + a] = point_forward<NI>(ws[q], b0, b1, has_next, L, T);
+          b0 = b1;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace tsff
+
+#include "tsff_api.inc"

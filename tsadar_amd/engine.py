@@ -1,0 +1,365 @@
+"""Engine: builds the static ``tsff_config`` from a tsadar input deck and drives libtsff.so.
+
+Device memory is held in torch CUDA tensors (torch is plumbing here: allocation, streams,
+torch.distributed); every compute step is a HIP kernel inside libtsff.so reached through the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib as L
+from . import distribution as D
+from .params import SlotMap
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DATA = os.path.join(_HERE, "data")
+
+C_LIGHT = 2.99792458e10
+
+
+def xi_grids():
+    """form_factor.py:128-138."""
+    minmax, h1 = 8.2, 1024
+    xi1 = np.linspace(-minmax - np.sqrt(2.0) / h1, minmax + np.sqrt(2.0) / h1, h1)
+    xi2 = np.arange(-minmax, minmax, 0.01)
+    return xi1, xi2
+
+
+def zprime_tables(xi2):
+    """form_factor.py:20-45 restricted to |xi| <= 10: linear interpolation of the shipped tables."""
+    rd = np.loadtxt(os.path.join(_DATA, "rdWT.txt"))
+    im = np.loadtxt(os.path.join(_DATA, "idWT.txt"))
+    return np.interp(xi2, rd[:, 0], rd[:, 1]), np.interp(xi2, im[:, 0], im[:, 1])
+
+
+def wavelength_axis_nm(lam_range, npts):
+    """The axis the reference hands to the IRF: lamAxis = squeeze(2 pi c / omgs) * 1e7
+    (form_factor.py:132-135, 293; generate_spectra.py:163, 191)."""
+    lam = np.linspace(lam_range[0], lam_range[1], npts)
+    omgs = 2e7 * np.pi * C_LIGHT / lam
+    return (2 * np.pi * C_LIGHT / omgs) * 1e7
+
+
+def gaussian_taps(lam_nm, stddev, cutoff_sigmas):
+    """Taps of ``jnp.convolve(x, g, "same")`` with g the Gaussian of irf.py:66-72 / 110-114 sampled
+    on the full wavelength axis: y[j] = sum_d g[c + d] x[j - d], c = (n - 1) // 2.  Taps further than
+    ``cutoff_sigmas`` standard deviations from the origin are dropped (their relative weight is
+    below exp(-cutoff^2 / 2)); ``cutoff_sigmas <= 0`` keeps every non-zero tap."""
+    n = lam_nm.size
+    origin = (np.amax(lam_nm) + np.amin(lam_nm)) / 2.0
+    g = (1.0 / (stddev * np.sqrt(2.0 * np.pi))) * np.exp(-((lam_nm - origin) ** 2.0) / (2.0 * stddev**2.0))
+    c = (n - 1) // 2
+    if cutoff_sigmas and cutoff_sigmas > 0:
+        keep = np.nonzero(np.abs(lam_nm - origin) <= cutoff_sigmas * stddev)[0]
+    else:
+        keep = np.nonzero(g > 0)[0]
+    lo, hi = int(keep[0]), int(keep[-1])
+    return np.ascontiguousarray(g[lo : hi + 1]), lo - c
+
+
+def _as_c(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    ptr_t = L.c_double_p if dtype == np.float64 else L.c_uint8_p
+    return a, a.ctypes.data_as(ptr_t)
+
+
+class Engine:
+    """One libtsff handle for one (deck, scattering angles) pair on the current CUDA/HIP device."""
+
+    def __init__(self, cfg: Dict, scattering_angles: Dict, activate: bool = True, fe_shared: Optional[np.ndarray] = None,
+                 fe_mode: Optional[int] = None, irf_cutoff_sigmas: float = 12.0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise L.TsffError("tsadar_amd needs a HIP device (no CPU fallback)")
+        self.torch = torch
+        self.lib = L.load()
+        self.cfg = cfg
+        other, data = cfg["other"], cfg["data"]
+        ext = other["extraoptions"]
+        self.slots = SlotMap(cfg["parameters"], activate)
+        sm = self.slots
+        self.n_ion, self.NP = sm.n_ion, sm.NP
+        self.npts = int(other["npts"])
+        self.load_ele, self.load_ion = bool(ext["load_ele_spec"]), bool(ext["load_ion_spec"])
+        if other.get("iawoff", 0):
+            raise NotImplementedError("iawoff cannot run under vmap in the reference (generate_spectra.py:199-208)")
+        gen = cfg["parameters"]["general"]
+        assert gen["Te_gradient"]["num_grad_points"] == gen["ne_gradient"]["num_grad_points"], \
+            "Number of gradient points for Te and ne must be the same"  # generate_spectra.py:70-73
+        fecfg = cfg["parameters"]["electron"]["fe"]
+        if fecfg.get("dim", 1) != 1:
+            raise NotImplementedError("2-D distribution functions are outside the 1-D form-factor path")
+        self.nvx = int(fecfg["nvx"])
+
+        c = L.TsffConfig()
+        keep = []  # numpy arrays referenced by the struct
+        c.abi_version = L.ABI_VERSION
+        c.lamrangE[:] = [float(v) for v in other["lamrangE"]]
+        c.lamrangI[:] = [float(v) for v in other["lamrangI"]]
+        c.npts = self.npts
+        c.load_ele, c.load_ion = int(self.load_ele), int(self.load_ion)
+        c.ele_lam_shift = float(data.get("ele_lam_shift", 0.0))
+        sa = np.asarray(scattering_angles["sa"], dtype=np.float64)
+        w0 = np.asarray(scattering_angles["weights"])[0]  # generate_spectra.py:165,197
+        w = np.broadcast_to(np.asarray(w0, dtype=np.float64), sa.shape)
+        c.n_angles = sa.size
+        a, c.sa_deg = _as_c(sa, np.float64); keep.append(a)
+        a, c.sa_weights = _as_c(w, np.float64); keep.append(a)
+        c.num_grad_points = int(gen["Te_gradient"]["num_grad_points"])
+        c.n_ion = sm.n_ion
+        c.nvx = self.nvx
+
+        # distribution function mode
+        if fe_mode is None:
+            if fe_shared is not None:
+                fe_mode = L.FE_SHARED
+            elif sm.fe_type == "dlm":
+                fe_mode = L.FE_DLM if fecfg.get("active", False) else L.FE_SHARED
+            else:
+                fe_mode = L.FE_PER_LINEOUT
+        self.fe_mode = fe_mode
+        c.fe_mode = fe_mode
+        if fe_mode == L.FE_SHARED:
+            if fe_shared is None:
+                if sm.fe_type != "dlm":
+                    raise NotImplementedError(f"Unknown 1D distribution type: {fecfg['type']}")
+                fe_shared = D.dlm(float(fecfg["params"]["m"]["val"]), self.nvx)
+            a, c.fe_shared = _as_c(fe_shared, np.float64); keep.append(a)
+            self.fe_shared = a
+        if fe_mode == L.FE_DLM:
+            a, c.dlm_table = _as_c(D.dlm_table(self.nvx), np.float64); keep.append(a)
+
+        xi1, xi2 = xi_grids()
+        assert xi1.size == L.NXI1 and xi2.size == L.NXI2
+        zr, zi = zprime_tables(xi2)
+        for name, arr in (("xi1", xi1), ("xi2", xi2), ("zprime_re", zr), ("zprime_im", zi)):
+            a, p = _as_c(arr, np.float64); keep.append(a); setattr(c, name, p)
+
+        # instrument response
+        phys = other["PhysParams"]
+        c.norm = int(phys["norm"])
+        lamE = wavelength_axis_nm(other["lamrangE"], self.npts)
+        lamI = wavelength_axis_nm(other["lamrangI"], self.npts)
+        if self.load_ele:
+            t, d0 = gaussian_taps(lamE, float(phys["widIRF"]["spect_stddev_ele"]), irf_cutoff_sigmas)
+            a, c.taps_ele = _as_c(t, np.float64); keep.append(a)
+            c.n_taps_ele, c.tap_dmin_ele = t.size, d0
+        if self.load_ion and phys["widIRF"]["spect_stddev_ion"]:
+            t, d0 = gaussian_taps(lamI, float(phys["widIRF"]["spect_stddev_ion"]), irf_cutoff_sigmas)
+            a, c.taps_ion = _as_c(t, np.float64); keep.append(a)
+            c.n_taps_ion, c.tap_dmin_ion = t.size, d0
+        filt = other.get("iawfilter", [0, 0, 0, 0])
+        if self.load_ele and filt[0]:
+            fb, fr = filt[3] - filt[2] / 2, filt[3] + filt[2] / 2
+            if other["lamrangE"][0] < fr and other["lamrangE"][1] > fb:
+                mult = np.where((fb < lamE) & (fr > lamE), 10.0 ** (-filt[1]), 1.0)
+                a, c.ele_filter = _as_c(mult, np.float64); keep.append(a)
+
+        # parameter transform
+        a, c.p_scale = _as_c(sm.scale, np.float64); keep.append(a)
+        a, c.p_shift = _as_c(sm.shift, np.float64); keep.append(a)
+        a, c.p_sigmoid = _as_c(sm.sigmoid, np.uint8); keep.append(a)
+        c.ti_same[:] = [int(v) for v in sm.ti_same]
+
+        # loss masks on the binned axes (loss_function.py:224-259)
+        method = cfg.get("optimizer", {}).get("loss_method", "l2")
+        if method not in L.LOSS_METHODS:
+            raise NotImplementedError(f"loss_method {method}")
+        c.loss_method = L.LOSS_METHODS[method]
+        ppp = self.npts // L.NBINS
+        self.lamE_bin = lamE.reshape(L.NBINS, ppp).mean(axis=1)
+        self.lamI_bin = lamI.reshape(L.NBINS, ppp).mean(axis=1)
+        r = data["fit_rng"]
+        mE = np.zeros(L.NBINS, dtype=np.uint8)
+        mI = np.zeros(L.NBINS, dtype=np.uint8)
+        if ext.get("fit_EPWb", False):
+            mE |= ((self.lamE_bin > r["blue_min"]) & (self.lamE_bin < r["blue_max"])).astype(np.uint8)
+        if ext.get("fit_EPWr", False):
+            mE |= (((self.lamE_bin > r["red_min"]) & (self.lamE_bin < r["red_max"])).astype(np.uint8) << 1)
+        if ext.get("fit_IAW", False):
+            mI |= (((self.lamI_bin > r["iaw_min"]) & (self.lamI_bin < r["iaw_cf_min"]))
+                   | ((self.lamI_bin > r["iaw_cf_max"]) & (self.lamI_bin < r["iaw_max"]))).astype(np.uint8)
+        self.mask_ele, self.mask_ion = mE, mI
+        a, c.mask_ele = _as_c(mE, np.uint8); keep.append(a)
+        a, c.mask_ion = _as_c(mI, np.uint8); keep.append(a)
+        self.n_blue = int(np.count_nonzero(mE & 1))
+        self.n_red = int(np.count_nonzero(mE & 2))
+        self.n_iaw = int(np.count_nonzero(mI & 1))
+        self.fit_blue, self.fit_red, self.fit_iaw = bool(ext.get("fit_EPWb")), bool(ext.get("fit_EPWr")), bool(ext.get("fit_IAW"))
+
+        self._keep = keep
+        self._cfg_struct = c
+        h = C.c_void_p()
+        rc = self.lib.tsff_create(C.byref(c), C.byref(h))
+        L.check(self.lib, None, rc)
+        self.h = h
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        # axes as the library computed them
+        ae, ai = np.zeros(L.NBINS), np.zeros(L.NBINS)
+        L.check(self.lib, self.h, self.lib.tsff_get_axes(self.h, ae.ctypes.data_as(L.c_double_p), ai.ctypes.data_as(L.c_double_p)))
+        self.lamAxisE, self.lamAxisI = ae, ai
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            self.lib.tsff_destroy(h)
+            self.h = None
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def dev(self, a, dtype=None):
+        """numpy / torch -> contiguous float64 CUDA tensor on this engine's device (no copy if it
+        already is one)."""
+        torch = self.torch
+        if a is None:
+            return None
+        if isinstance(a, torch.Tensor):
+            t = a
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64)))
+        return t.to(device=self.device, dtype=dtype or torch.float64).contiguous()
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+    def _sync_stream(self):
+        s = self.torch.cuda.current_stream(self.device)
+        L.check(self.lib, self.h, self.lib.tsff_set_stream(self.h, C.c_void_p(s.cuda_stream)))
+
+    def _vec(self, a, B):
+        """amplitude-like input -> [B] device vector."""
+        t = self.dev(a).reshape(-1)
+        if t.numel() == 1 and B > 1:
+            t = t.expand(B).contiguous()
+        assert t.numel() == B, f"expected {B} amplitudes, got {t.numel()}"
+        return t
+
+    def _mat(self, a, B):
+        """noise/data-like input -> [B, 1024] device matrix or None for an all-zero scalar."""
+        if a is None:
+            return None
+        if not isinstance(a, self.torch.Tensor):
+            arr = np.asarray(a, dtype=np.float64)
+            if arr.size == 1 and float(arr.reshape(-1)[0]) == 0.0:
+                return None
+            if arr.size != B * L.NBINS:
+                arr = np.broadcast_to(arr.reshape(-1, 1) if arr.ndim <= 1 and arr.size in (1, B) else arr, (B, L.NBINS))
+            a = arr
+        t = self.dev(a)
+        return t.reshape(B, L.NBINS).contiguous()
+
+    # ---- entry points ---------------------------------------------------------------------------
+    def chi_table(self, fe):
+        torch = self.torch
+        fe_d = self.dev(fe).reshape(-1, self.nvx)
+        W = torch.empty((fe_d.shape[0], L.NXI2), dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        L.check(self.lib, self.h, self.lib.tsff_chi_table(self.h, self._ptr(fe_d), fe_d.shape[0], self._ptr(W)))
+        return W
+
+    def form_factor(self, feature, phys, fe=None):
+        """Raw FormFactor.__call__: phys [B, NP] PHYSICAL parameters -> P [B, G, npts, n_angles]."""
+        torch = self.torch
+        phys_d = self.dev(phys).reshape(-1, self.NP)
+        B = phys_d.shape[0]
+        fe_d = self.dev(fe)
+        G, NA = int(self._cfg_struct.num_grad_points), int(self._cfg_struct.n_angles)
+        P = torch.empty((B, G, self.npts, NA), dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        L.check(self.lib, self.h, self.lib.tsff_form_factor(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), B, self._ptr(P)))
+        return P
+
+    def forward(self, params, e_amps, i_amps, noise_e=None, noise_i=None, fe=None):
+        torch = self.torch
+        X = self.dev(params).reshape(-1, self.NP)
+        B = X.shape[0]
+        ea = self._vec(e_amps, B) if self.load_ele else None
+        ia = self._vec(i_amps, B) if self.load_ion else None
+        ne_, ni_ = self._mat(noise_e, B), self._mat(noise_i, B)
+        fe_d = self.dev(fe)
+        E = torch.zeros((B, L.NBINS), dtype=torch.float64, device=self.device)
+        I = torch.zeros((B, L.NBINS), dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        rc = self.lib.tsff_forward(self.h, self._ptr(X), self._ptr(fe_d), self._ptr(ea), self._ptr(ia), self._ptr(ne_),
+                                   self._ptr(ni_), B, self._ptr(E), self._ptr(I))
+        L.check(self.lib, self.h, rc)
+        return E, I
+
+    def loss_weights(self, B_global, i_norm, e_norm, ion_loss_scale=1.0):
+        """The factor each masked sum carries in the total loss (loss_function.py:190-267, 335-338)
+        for a nanmean over B_global x 1024 entries and constant denominators i_norm^2 / e_norm^2."""
+        c = 0.5 if (self.fit_blue and self.fit_red) else 1.0
+        w = np.zeros(3)
+        if self.fit_iaw and self.n_iaw:
+            w[0] = ion_loss_scale / (B_global * self.n_iaw * i_norm**2)
+        if self.fit_blue and self.n_blue:
+            w[1] = c / (B_global * self.n_blue * e_norm**2)
+        if self.fit_red and self.n_red:
+            # the reference halves (blue + red) only when blue is fitted too (:262-264)
+            w[2] = c / (B_global * self.n_red * e_norm**2)
+        if self.cfg.get("optimizer", {}).get("loss_method", "l2") in ("log-cosh", "poisson"):
+            # these functionals ignore the denominator (loss_function.py:414-417)
+            w[0] *= i_norm**2
+            w[1] *= e_norm**2
+            w[2] *= e_norm**2
+        return w
+
+    def loss_grad(self, params, batch, weights, grad_mask, fe=None, want_spectra=False, out=None):
+        """-> (loss_terms[3], grad[B, NP], ThryE, ThryI) as CUDA tensors; nothing is synchronised."""
+        torch = self.torch
+        X = self.dev(params).reshape(-1, self.NP)
+        B = X.shape[0]
+        ea = self._vec(batch["e_amps"], B) if self.load_ele else None
+        ia = self._vec(batch["i_amps"], B) if self.load_ion else None
+        ed = self._mat(batch["e_data"], B) if self.load_ele else None
+        idt = self._mat(batch["i_data"], B) if self.load_ion else None
+        ne_, ni_ = self._mat(batch.get("noise_e"), B), self._mat(batch.get("noise_i"), B)
+        fe_d = self.dev(fe)
+        if out is None:
+            terms = torch.empty(3, dtype=torch.float64, device=self.device)
+            grad = torch.empty((B, self.NP), dtype=torch.float64, device=self.device)
+        else:
+            terms, grad = out
+        E = torch.zeros((B, L.NBINS), dtype=torch.float64, device=self.device) if want_spectra else None
+        I = torch.zeros((B, L.NBINS), dtype=torch.float64, device=self.device) if want_spectra else None
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        gm = np.ascontiguousarray(grad_mask, dtype=np.uint8)
+        self._sync_stream()
+        rc = self.lib.tsff_loss_grad(self.h, self._ptr(X), self._ptr(fe_d), self._ptr(ed), self._ptr(idt), self._ptr(ea),
+                                     self._ptr(ia), self._ptr(ne_), self._ptr(ni_), B, w.ctypes.data_as(L.c_double_p),
+                                     gm.ctypes.data_as(L.c_uint8_p), self._ptr(terms), self._ptr(grad), self._ptr(E), self._ptr(I))
+        L.check(self.lib, self.h, rc)
+        return terms, grad, E, I
+
+    def array_loss(self, params, batch, fe=None):
+        torch = self.torch
+        X = self.dev(params).reshape(-1, self.NP)
+        B = X.shape[0]
+        ea = self._vec(batch["e_amps"], B) if self.load_ele else None
+        ia = self._vec(batch["i_amps"], B) if self.load_ion else None
+        ed = self._mat(batch["e_data"], B) if self.load_ele else None
+        idt = self._mat(batch["i_data"], B) if self.load_ion else None
+        ne_, ni_ = self._mat(batch.get("noise_e"), B), self._mat(batch.get("noise_i"), B)
+        fe_d = self.dev(fe)
+        z = lambda: torch.zeros((B, L.NBINS), dtype=torch.float64, device=self.device)
+        sums = torch.zeros((B, 3), dtype=torch.float64, device=self.device)
+        sqe, sqi, E, I = z(), z(), z(), z()
+        self._sync_stream()
+        rc = self.lib.tsff_array_loss(self.h, self._ptr(X), self._ptr(fe_d), self._ptr(ed), self._ptr(idt), self._ptr(ea),
+                                      self._ptr(ia), self._ptr(ne_), self._ptr(ni_), B, self._ptr(sums), self._ptr(sqe),
+                                      self._ptr(sqi), self._ptr(E), self._ptr(I))
+        L.check(self.lib, self.h, rc)
+        return sums, sqe, sqi, E, I
+
+    def enable_timing(self, on=True):
+        L.check(self.lib, self.h, self.lib.tsff_enable_timing(self.h, int(on)))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        L.check(self.lib, self.h, self.lib.tsff_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)
