@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: spectra/s for forward + gradient of one EPW(1024 lambda) + IAW(1024 lambda)
+spectrum, batch 4096 per GPU, P = 6 free parameters (BASELINE.json metric, configs[2] / configs[4]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one evaluation of loss + gradient (tsff_loss_grad) over this rank's 4096 lineouts, with the
+inputs (params, data, amplitudes) already resident in HBM, plus -- for N > 1 -- the single RCCL
+all-reduce of [3 loss sums | gradient] (weak scaling: 4096 lineouts per GPU).  Rank 0 prints ONE JSON
+line.  The oracle is used only for the ``cpu_baseline`` leg (rank 0, N = 1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12      # B/s, spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+FP64_PEAK = 78.6e12    # flop/s, AMD public spec for FP64 vector (not in the local guide)
+FLOP_PER_SPECTRUM = 13.0e6  # forward + adjoint, shared W table
+
+
+def algorithmic_bytes(NP: int, with_noise: bool) -> int:
+    """SURVEY.md section 8d, per spectrum (EPW + IAW), forward + gradient."""
+    rd = 2 * 1024 * 8 + 2 * 8 + NP * 8 + (2 * 1024 * 8 if with_noise else 0)
+    wr = NP * 8 + 3 * 8
+    return rd + wr
+
+
+def _cpu_worker_init():
+    import torch
+
+    torch.set_num_threads(1)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import tsadar_oracle_torch  # noqa: F401  (import cost outside the timed region)
+
+
+def _cpu_worker(args):
+    cfg, sa, normed, batch, i_norm, e_norm, names = args
+    from oracle import tsadar_oracle_torch as ot
+
+    val, g, _, _ = ot.value_and_grad(cfg, sa, normed, batch, i_norm, e_norm, names)
+    return val
+
+
+def cpu_baseline(cfg, B, n_sample):
+    """Oracle (CPU restatement of the reference algorithm; torch float64 autograd stands in for the
+    reference's JAX autodiff) on the first ``n_sample`` lineouts of the same seeded draw, one lineout
+    per task, spread over the host cores with a process pool.  Runs BEFORE this process touches the
+    GPU (no fork after HIP initialisation).  Returns the ``cpu_baseline`` object."""
+    import multiprocessing as mp
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import tsadar_oracle as orc
+    from tsadar_amd import _lib as L
+    from tsadar_amd import synthetic as S
+    from tsadar_amd.calibration import sa_lookup
+
+    n = n_sample
+    rng = np.random.default_rng(S.SEED)
+    truth = S.draw_params(cfg, B, rng)
+    rng.integers(1 << 31)  # the draw make_batch() consumes on the GPU leg
+    guess = S.draw_params(cfg, B, rng)
+    p9 = sa_lookup("P9")
+    sa1 = dict(sa=p9["sa"], weights=p9["weights"] * np.ones([1, 10]))
+
+    def named(X, b):
+        return {
+            "Te": X[b:b + 1, L.P_TE], "ne": X[b:b + 1, L.P_NE], "m": X[b:b + 1, L.P_M],
+            "Ti_1": X[b:b + 1, L.P_ION0 + L.ION_TI], "Z_1": X[b:b + 1, L.P_ION0 + L.ION_Z],
+            "A_1": X[b:b + 1, L.P_ION0 + L.ION_A], "fract_1": X[b:b + 1, L.P_ION0 + L.ION_FRACT],
+            "lam": X[b:b + 1, L.P_LAM], "amp1": X[b:b + 1, L.P_AMP1], "amp2": X[b:b + 1, L.P_AMP2],
+            "amp3": X[b:b + 1, L.P_AMP3], "ne_gradient": X[b:b + 1, L.P_NE_GRADIENT],
+            "Te_gradient": X[b:b + 1, L.P_TE_GRADIENT], "ud": X[b:b + 1, L.P_UD], "Va": X[b:b + 1, L.P_VA],
+        }
+
+    unit = dict(e_amps=np.ones(1), i_amps=np.ones(1), noise_e=np.zeros((1, 1024)), noise_i=np.zeros((1, 1024)))
+    nrng = np.random.default_rng(S.SEED + 1)
+    names = ["Te", "ne", "Ti_1", "Va", "lam", "amp1"]
+    tasks = []
+    for b in range(n):
+        E, I, lE, lI = orc.ts_diag(cfg, sa1, named(truth.X, b), unit)
+        E = E * (1 + 0.01 * nrng.standard_normal(E.shape))
+        I = I * (1 + 0.01 * nrng.standard_normal(I.shape))
+        iaw, blue, red = orc.fit_masks(cfg, lE, lI)
+        bt = dict(e_data=E, i_data=I, e_amps=np.array([E[0][blue[0] | red[0]].max()]), i_amps=np.array([I[0][iaw[0]].max()]),
+                  noise_e=np.zeros((1, 1024)), noise_i=np.zeros((1, 1024)))
+        tasks.append((cfg, sa1, named(guess.X, b), bt, float(I.max()), float(E.max()), names))
+    cores = max(1, min(os.cpu_count() or 1, 16, n))
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores, initializer=_cpu_worker_init) as pool:
+        pool.map(_cpu_worker, tasks[:cores])  # warm-up: imports, W-table cache, allocator
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker, tasks, chunksize=1)
+        dt = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
+        "sample": (f"first {n} of the {B} lineouts (same seeded parameter draws), loss+grad of one EPW+IAW spectrum each by "
+                   f"torch-f64 reverse-mode autodiff of the oracle (CPU restatement of the reference algorithm, W table cached), "
+                   f"{cores} processes x 1 thread, {dt:.1f} s wall"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="lineouts per GPU")
+    ap.add_argument("--ppp", type=int, default=1, help="points per pixel (1 -> 1024 wavelength points per feature)")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="lineouts of the CPU baseline (0 = skip)")
+    ap.add_argument("--forward-only", action="store_true", help="configs[1]: forward-only (not the headline metric)")
+    args = ap.parse_args()
+
+    from tsadar_amd import synthetic as S
+
+    cpu_res = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_sample > 0 and not args.forward_only:
+        cpu_res = cpu_baseline(S.baseline_deck(points_per_pixel=args.ppp, batch_size=args.batch), args.batch, args.cpu_sample)
+
+    import torch
+
+    from tsadar_amd import distributed as D
+    from tsadar_amd.engine import Engine
+
+    world, rank, local = D.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+
+    B = args.batch
+    cfg = S.baseline_deck(points_per_pixel=args.ppp, batch_size=B)
+    from tsadar_amd.calibration import sa_lookup
+
+    sa = sa_lookup("P9")
+    sa = dict(sa=sa["sa"], weights=sa["weights"] * np.ones([B, 10]))  # lineouts.py:103
+    eng = Engine(cfg, sa, activate=True)
+
+    # synthetic inputs: each rank draws its own shard (seed offset by rank), data generated on the GPU
+    rng = np.random.default_rng(S.SEED + rank)
+    truth = S.draw_params(cfg, B, rng)
+    batch = S.make_batch(eng, truth, rng)
+    guess = S.draw_params(cfg, B, rng)
+    X = eng.dev(guess.to_matrix())
+    gmask = guess.grad_mask()
+    act = torch.tensor([s for _, s in guess.slots.active_leaves], device=dev)
+    P = int(act.numel())
+    e_norm = float(batch["e_data"].max())
+    i_norm = float(batch["i_data"].max())
+    w = eng.loss_weights(B * world, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    terms = torch.empty(3, dtype=torch.float64, device=dev)
+    grad = torch.empty((B, eng.NP), dtype=torch.float64, device=dev)
+    E_out = torch.empty((B, 1024), dtype=torch.float64, device=dev)
+    I_out = torch.empty((B, 1024), dtype=torch.float64, device=dev)
+
+    def step():
+        if args.forward_only:
+            return eng.forward(X, batch["e_amps"], batch["i_amps"])
+        eng.loss_grad(X, batch, w, gmask, out=(terms, grad))
+        g = grad[:, act].t().contiguous()
+        return D.allreduce_loss_grad(terms, g, world, rank)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.enable_timing(max(args.steps, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ktimes = eng.kernel_times_ms()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+
+    # PCIe-inclusive variant (what a host L-BFGS step pays): params H2D + loss/grad D2H every step
+    pcie_value = None
+    if world == 1 and not args.forward_only:
+        Xh = guess.to_matrix()
+        eng.enable_timing(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            Xd = eng.dev(Xh)
+            eng.loss_grad(Xd, batch, w, gmask, out=(terms, grad))
+            host = torch.cat([terms, grad[:, act].t().reshape(-1)]).cpu()
+        torch.cuda.synchronize()
+        pcie_value = B * args.steps / (time.perf_counter() - t1)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    kavg_s = float(np.mean(ktimes)) * 1e-3 if ktimes.size else float("nan")
+    abytes = algorithmic_bytes(eng.NP, with_noise=False) if not args.forward_only else (eng.NP * 8 + 16 + 2 * 1024 * 8)
+    achieved = B * abytes / kavg_s / 1e9
+    res = {
+        "metric": "spectra/sec (fwd+grad), 1024-lambda EPW+IAW form factor, batch 4096" if not args.forward_only
+        else "spectra/sec (forward only), 1024-lambda EPW+IAW form factor",
+        "value": value,
+        "unit": "spectra/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": ("configs[2]: batch 4096 EPW+IAW spectra forward+adjoint (loss+grad as inside the L-BFGS fit loop), "
+                         "6 free params {Te, ne, Ti, Va, lam, amp1}, Maxwellian f_e (shared W table)")
+            if not args.forward_only else "configs[1]-like: forward-only EPW+IAW spectra, Maxwellian f_e",
+            "lineouts_per_gpu": B,
+            "global_batch": B * world,
+            "n_lambda": 1024 * args.ppp,
+            "n_angles": 10,
+            "free_params": P,
+            "parallelism": f"lineout-sharded x{world}, one all-reduce of [3 + B*P] f64 per step" if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": achieved * 1e9 / HBM_PEAK,
+            "traffic": None,
+            "kernel": "k_spectrum<1,1>" if not args.forward_only else "k_spectrum<1,0>",
+            "kernel_avg_ms": kavg_s * 1e3,
+            "algorithmic_bytes_per_spectrum": abytes,
+            "note": "the path is FP64-VALU bound (SURVEY.md 8d); see roofline_fp64",
+        },
+        "roofline_fp64": {
+            "bound": "fp64-valu",
+            "achieved": B * FLOP_PER_SPECTRUM / kavg_s / 1e12,
+            "peak": FP64_PEAK / 1e12,
+            "unit": "TFLOP/s",
+            "frac": B * FLOP_PER_SPECTRUM / kavg_s / FP64_PEAK,
+            "algorithmic_flop_per_spectrum": FLOP_PER_SPECTRUM,
+        },
+    }
+    if pcie_value is not None:
+        res["value_pcie_inclusive"] = pcie_value
+    if cpu_res is not None:
+        res["cpu_baseline"] = cpu_res
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

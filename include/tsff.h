@@ -182,10 +182,12 @@ int tsff_array_loss(tsff_handle *h, const double *params, const double *fe, cons
                     const double *noise_e, const double *noise_i, int32_t B, double *sums,
                     double *sqdev_e, double *sqdev_i, double *ThryE, double *ThryI);
 
-/* timing of the last tsff_forward / tsff_loss_grad main kernel, measured with HIP events on the
- * handle's stream (enable first; adds two event records per call). */
-int tsff_enable_timing(tsff_handle *h, int32_t on);
-int tsff_last_kernel_ms(tsff_handle *h, float *ms);
+/* HIP-event timing of the main kernel (k_spectrum) of tsff_forward / tsff_loss_grad /
+ * tsff_array_loss on the handle's stream.  tsff_enable_timing(h, ring) keeps one event pair per
+ * launch in a ring of `ring` entries (0 disables); tsff_kernel_times returns the durations [ms] of
+ * the most recent min(ring, launches, max_n) launches, oldest first, and synchronises on them. */
+int tsff_enable_timing(tsff_handle *h, int32_t ring);
+int tsff_kernel_times(tsff_handle *h, float *ms, int32_t max_n, int32_t *n_out);
 
 #ifdef __cplusplus
 }

@@ -89,7 +89,7 @@ _SIGNATURES = {
     "tsff_loss_grad": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, _vp, _vp, _vp, _vp]),
     "tsff_array_loss": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "tsff_enable_timing": (C.c_int, [_vp, C.c_int32]),
-    "tsff_last_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "tsff_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

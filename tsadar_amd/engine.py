@@ -356,10 +356,12 @@ class Engine:
         L.check(self.lib, self.h, rc)
         return sums, sqe, sqi, E, I
 
-    def enable_timing(self, on=True):
-        L.check(self.lib, self.h, self.lib.tsff_enable_timing(self.h, int(on)))
+    def enable_timing(self, ring: int = 256):
+        """Record one HIP event pair around every main-kernel launch (ring of ``ring`` launches)."""
+        L.check(self.lib, self.h, self.lib.tsff_enable_timing(self.h, int(ring)))
 
-    def last_kernel_ms(self) -> float:
-        ms = C.c_float()
-        L.check(self.lib, self.h, self.lib.tsff_last_kernel_ms(self.h, C.byref(ms)))
-        return float(ms.value)
+    def kernel_times_ms(self, max_n: int = 65536) -> np.ndarray:
+        buf = (C.c_float * max_n)()
+        n = C.c_int32()
+        L.check(self.lib, self.h, self.lib.tsff_kernel_times(self.h, buf, max_n, C.byref(n)))
+        return np.array(buf[: n.value], dtype=np.float64)
