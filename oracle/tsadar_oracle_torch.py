@@ -258,31 +258,48 @@ def ts_diag(cfg, sa, normed, batch, activate=True, fe_batch=None):
     return st(outE), st(outI), st(lamE), st(lamI)
 
 
-def loss(cfg, sa, normed, batch, i_norm, e_norm, activate=True, fe_batch=None):
-    """loss_function.py:364-373 (nanmean over the masked entries of the whole batch)."""
+def masked_sums(cfg, sa, normed, batch, activate=True, fe_batch=None):
+    """Un-normalised masked sums [S_iaw, S_blue, S_red] of the loss functional over the given lineouts,
+    the number of fitted entries of each, and the spectra (loss_function.py:190-267 before the mean)."""
     ThryE, ThryI, lamE, lamI = ts_diag(cfg, sa, normed, batch, activate, fe_batch)
     ext = cfg["other"]["extraoptions"]
     method = cfg["optimizer"]["loss_method"]
     iaw, blue, red = orc.fit_masks(cfg, lamE.detach().numpy(), lamI.detach().numpy())
 
-    def fun(d, t, u):
+    def fun(d, t):
         d = _t(d)
         if method == "l1":
-            return torch.abs(d - t) / u
+            return torch.abs(d - t)
         if method == "l2":
-            return torch.square(d - t) / u
+            return torch.square(d - t)
         if method == "log-cosh":
             return torch.log(torch.cosh(d - t))
         return t - d * torch.log(t)
 
-    i_err = torch.zeros((), dtype=DT)
-    e_err = torch.zeros((), dtype=DT)
+    z = torch.zeros((), dtype=DT)
+    S = [z, z, z]
+    N = [0, 0, 0]
     if ext["fit_IAW"]:
-        i_err = i_err + fun(batch["i_data"], ThryI, i_norm**2)[torch.as_tensor(iaw)].mean()
+        S[0], N[0] = fun(batch["i_data"], ThryI)[torch.as_tensor(iaw)].sum(), int(iaw.sum())
     if ext["fit_EPWb"]:
-        e_err = e_err + fun(batch["e_data"], ThryE, e_norm**2)[torch.as_tensor(blue)].mean()
+        S[1], N[1] = fun(batch["e_data"], ThryE)[torch.as_tensor(blue)].sum(), int(blue.sum())
     if ext["fit_EPWr"]:
-        e_err = e_err + fun(batch["e_data"], ThryE, e_norm**2)[torch.as_tensor(red)].mean()
+        S[2], N[2] = fun(batch["e_data"], ThryE)[torch.as_tensor(red)].sum(), int(red.sum())
+    return torch.stack(S), N, ThryE, ThryI
+
+
+def loss(cfg, sa, normed, batch, i_norm, e_norm, activate=True, fe_batch=None):
+    """loss_function.py:364-373 (nanmean over the masked entries of the whole batch)."""
+    S, N, ThryE, ThryI = masked_sums(cfg, sa, normed, batch, activate, fe_batch)
+    ext = cfg["other"]["extraoptions"]
+    dep = cfg["optimizer"]["loss_method"] in ("l1", "l2")  # the other functionals ignore the denominator
+    ui, ue = (i_norm**2, e_norm**2) if dep else (1.0, 1.0)
+    i_err = S[0] / (N[0] * ui) if ext["fit_IAW"] else torch.zeros((), dtype=DT)
+    e_err = torch.zeros((), dtype=DT)
+    if ext["fit_EPWb"]:
+        e_err = e_err + S[1] / (N[1] * ue)
+    if ext["fit_EPWr"]:
+        e_err = e_err + S[2] / (N[2] * ue)
         if ext["fit_EPWb"]:
             e_err = e_err * 0.5
     return cfg["data"]["ion_loss_scale"] * i_err + e_err, ThryE, ThryI

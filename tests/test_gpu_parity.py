@@ -212,3 +212,161 @@ def test_gradient_tied_ion_temperature(torch_mod):
         cfg["parameters"]["ion-2"]["Ti"]["same"] = True
 
     _grad_case(torch_mod, ("Te", "ne", "Ti", "lam"), ["Te", "ne", "Ti_1", "Ti_2", "lam"], B=2, seed=17, n_ion=2, tweak=tweak)
+
+
+def test_committed_golden_fixture(torch_mod):
+    """tests/golden/oracle_fit_b4.npz (made by tests/golden/make_golden.py from the oracle): spectra,
+    loss, gradient and array_loss of four BASELINE lineouts through the drop-in LossFunction API."""
+    from tsadar_amd import ThomsonParams, tree
+    from tsadar_amd.loss_function import LossFunction
+
+    z = np.load("tests/golden/oracle_fit_b4.npz")
+    B = 4
+    cfg = decks.deck_fit(active=("Te", "ne", "Ti", "Va", "lam", "amp1"))
+    cfg["optimizer"]["batch_size"] = B
+    sa = util.sa_fit(B)
+    batch = {k: z[k] for k in ("e_data", "i_data", "e_amps", "i_amps", "noise_e", "noise_i")}
+    lf = LossFunction(cfg, sa, batch)
+    assert lf.i_norm == float(z["i_norm"]) and lf.e_norm == float(z["e_norm"])
+    tp = ThomsonParams(cfg["parameters"], B, batch=True, activate=True)
+    tp.X[:] = z["X"]
+    diff, static = tree.partition(tp, tree.get_filter_spec(cfg["parameters"], tp))
+    x0, lf.unravel_weights = tree.ravel_pytree(diff)
+    value, flat = lf.vg_loss(x0, static, batch)  # exactly how loops.py:43-51 calls it
+    assert isinstance(value, float) and flat.dtype == np.float64 and flat.shape == (6 * B,)
+    assert abs(value - float(z["loss"])) < 1e-9 * abs(float(z["loss"]))
+    # fixture columns: Te, ne, Ti_1, Va, lam, amp1; ravel order (pytree field order): Te, ne, Ti_1, lam, amp1, Va
+    gref = z["grad"][:, [0, 1, 2, 4, 5, 3]].T.reshape(-1)
+    assert np.max(np.abs(flat - gref)) < 1e-7 * np.max(np.abs(gref))
+    E, I, lamE, lamI = lf.ts_diag(tp, batch)
+    assert util.rel_err(E, z["ThryE"]) < 1e-8 and util.rel_err(I, z["ThryI"]) < 1e-8
+    assert lamE.shape == lamI.shape == (B, 1024)
+    total, sqdev, E2, I2, params = lf.array_loss(tp, batch)
+    np.testing.assert_allclose(total, z["array_loss"], rtol=1e-7)
+    np.testing.assert_allclose(sqdev["ele"], z["sqdev_ele"], rtol=1e-6, atol=1e-12 * z["sqdev_ele"].max())
+    np.testing.assert_allclose(sqdev["ion"], z["sqdev_ion"], rtol=1e-6, atol=1e-12 * z["sqdev_ion"].max())
+    assert set(params) == {"electron", "general", "ion-1"}
+
+
+def test_full_size_properties(torch_mod):
+    """BASELINE size (B = 4096, configs[2]) through size-independent properties: batch invariance
+    (a lineout's spectrum and gradient do not depend on its batch mates), linearity in the amplitudes,
+    additivity of the loss sums, 1/N scaling of the gradient; plus an oracle spot check of 3 of the 4096."""
+    from tsadar_amd import synthetic as S
+    from tsadar_amd.engine import Engine
+
+    B = 4096
+    cfg = S.baseline_deck(batch_size=B)
+    sa = util.sa_fit(B)
+    eng = Engine(cfg, sa)
+    rng = np.random.default_rng(S.SEED)
+    truth = S.draw_params(cfg, B, rng)
+    batch = S.make_batch(eng, truth, rng)
+    guess = S.draw_params(cfg, B, rng)
+    X = guess.to_matrix()
+    gm = guess.grad_mask()
+    e_norm, i_norm = float(batch["e_data"].max()), float(batch["i_data"].max())
+    w = eng.loss_weights(B, i_norm, e_norm)
+    terms, grad, E, I = eng.loss_grad(X, batch, w, gm, want_spectra=True)
+    terms, grad, E, I = terms.cpu().numpy(), grad.cpu().numpy(), E.cpu().numpy(), I.cpu().numpy()
+    assert np.all(np.isfinite(grad)) and np.all(np.isfinite(E)) and np.all(np.isfinite(I))
+    # batch invariance + 1/N scaling: re-evaluate a scattered subset on its own
+    idx = np.array([0, 1, 257, 1023, 2048, 4095])
+    sub = {k: (v[torch_mod.as_tensor(idx, device=v.device)] if v is not None else None) for k, v in batch.items()}
+    w_sub = eng.loss_weights(len(idx), i_norm, e_norm)
+    t2, g2, E2, I2 = eng.loss_grad(X[idx], sub, w_sub, gm, want_spectra=True)
+    np.testing.assert_array_equal(E2.cpu().numpy(), E[idx])
+    np.testing.assert_array_equal(I2.cpu().numpy(), I[idx])
+    np.testing.assert_allclose(g2.cpu().numpy() * (len(idx) / B), grad[idx], rtol=1e-12, atol=0)
+    # additivity: the batch sums are the sum of the per-lineout sums
+    per = np.stack([eng.loss_grad(X[i:i + 1], {k: (v[i:i + 1] if v is not None else None) for k, v in batch.items()},
+                                  w, gm)[0].cpu().numpy() for i in idx])
+    np.testing.assert_allclose(per.sum(axis=0), t2.cpu().numpy(), rtol=1e-12)
+    # linearity in the amplitudes (noise is zero): doubling e_amps doubles ThryE
+    E3, I3 = eng.forward(X[idx], 2 * sub["e_amps"], 3 * sub["i_amps"])
+    np.testing.assert_allclose(E3.cpu().numpy(), 2 * E[idx], rtol=1e-14)
+    np.testing.assert_allclose(I3.cpu().numpy(), 3 * I[idx], rtol=1e-14)
+    # oracle spot check
+    for b in (5, 1999, 4000):
+        normed = {k: X[b:b + 1, util.slot_of(k)] for k in
+                  ["Te", "ne", "m", "Ti_1", "Z_1", "A_1", "fract_1", "lam", "amp1", "amp2", "amp3", "ne_gradient", "Te_gradient", "ud", "Va"]}
+        bt = dict(e_amps=batch["e_amps"][b:b + 1].cpu().numpy(), i_amps=batch["i_amps"][b:b + 1].cpu().numpy(),
+                  noise_e=np.zeros((1, 1024)), noise_i=np.zeros((1, 1024)))
+        Eo, Io, _, _ = orc.ts_diag(cfg, util.sa_fit(1), normed, bt)
+        assert util.rel_err(E[b:b + 1], Eo) < 1e-8 and util.rel_err(I[b:b + 1], Io) < 1e-8
+
+
+def test_edge_cases(torch_mod):
+    """Single lineout; EPW-only and IAW-only decks; parameters at the edge of the sigmoid range;
+    every loss functional; non-zero drift and flow; zero-weight masks."""
+    from tsadar_amd.engine import Engine
+    from oracle import tsadar_oracle_torch as ot
+
+    for method in ("l2", "l1", "log-cosh", "poisson"):
+        cfg = decks.deck_fit(active=("Te", "ne", "Ti", "Va", "ud", "lam", "amp1", "amp2", "amp3"))
+        cfg["optimizer"]["loss_method"] = method
+        B = 2
+        sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B, seed=23)
+        normed["ud"] = np.array([0.45, 0.55])  # identity-free: 'ud' is active -> sigmoid -> [-10, 10]
+        eng = Engine(cfg, sa)
+        w = eng.loss_weights(B, i_norm, e_norm)
+        names = ["Te", "ne", "Ti_1", "Va", "ud", "lam", "amp1", "amp2", "amp3"]
+        terms, grad, _, _ = eng.loss_grad(util.normed_to_matrix(normed, 1), batch, w, eng.slots.active.astype(np.uint8))
+        val, ref, _, _ = ot.value_and_grad(cfg, sa, normed, batch, i_norm, e_norm, names)
+        assert abs(float(np.dot(terms.cpu().numpy(), w)) - val) < 1e-9 * abs(val), method
+        G = util.matrix_to_named(grad.cpu().numpy(), names)
+        scale = max(np.max(np.abs(v)) for v in ref.values())
+        for k in names:
+            assert np.max(np.abs(G[k] - ref[k])) < 1e-7 * scale, (method, k)
+    # EPW only / IAW only
+    for ele, ion in ((True, False), (False, True)):
+        cfg = decks.deck_fit()
+        ext = cfg["other"]["extraoptions"]
+        ext["load_ele_spec"], ext["load_ion_spec"] = ele, ion
+        ext["fit_EPWb"] = ext["fit_EPWr"] = ele
+        ext["fit_IAW"] = ion
+        B = 1
+        sa, batch, normed, i_norm, e_norm = _loss_setup(decks.deck_fit(), B, seed=29)
+        eng = Engine(cfg, sa)
+        E, I = eng.forward(util.normed_to_matrix(normed, 1), batch["e_amps"], batch["i_amps"], batch["noise_e"], batch["noise_i"])
+        Eo, Io, _, _ = orc.ts_diag(cfg, sa, normed, batch)
+        if ele:
+            assert util.rel_err(E.cpu().numpy(), Eo) < 1e-8 and float(I.abs().max()) == 0.0
+        else:
+            assert util.rel_err(I.cpu().numpy(), Io) < 1e-8 and float(E.abs().max()) == 0.0
+        w = eng.loss_weights(B, i_norm, e_norm)
+        terms, grad, _, _ = eng.loss_grad(util.normed_to_matrix(normed, 1), batch, w, eng.slots.active.astype(np.uint8))
+        lo, _, _ = orc.loss(cfg, sa, normed, batch, i_norm, e_norm)
+        assert abs(float(np.dot(terms.cpu().numpy(), w)) - lo) < 1e-9 * abs(lo)
+    # saturated sigmoids: physical values pinned at a bound, gradient finite and ~0
+    cfg = decks.deck_fit()
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, 1, seed=31)
+    normed["amp1"] = np.array([40.0])
+    normed["Va"] = np.array([-40.0])
+    normed["Te"] = np.array([3.0])
+    eng = Engine(cfg, sa)
+    w = eng.loss_weights(1, i_norm, e_norm)
+    terms, grad, _, _ = eng.loss_grad(util.normed_to_matrix(normed, 1), batch, w, eng.slots.active.astype(np.uint8))
+    g = grad.cpu().numpy()
+    assert np.all(np.isfinite(g)) and abs(g[0, 4]) < 1e-12
+
+
+def test_errors_are_reported_not_swallowed(torch_mod):
+    from tsadar_amd import _lib
+    from tsadar_amd.engine import Engine
+
+    cfg = decks.deck_fit(active=("Te", "ne", "m"))
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, 1, seed=37)
+    eng = Engine(cfg, sa)
+    with pytest.raises(_lib.TsffError, match="DLM order m"):
+        eng.loss_grad(util.normed_to_matrix(normed, 1), batch, eng.loss_weights(1, i_norm, e_norm), eng.slots.active.astype(np.uint8))
+    cfg = decks.deck_fit()
+    cfg["other"]["PhysParams"]["norm"] = 1
+    with pytest.raises(_lib.TsffError, match="norm"):
+        Engine(cfg, sa)
+    cfg = decks.deck_fit()
+    cfg["other"]["extraoptions"]["spectype"] = "bogus"
+    from tsadar_amd.diagnostic import ThomsonScatteringDiagnostic
+
+    with pytest.raises(NotImplementedError, match="Unknown spectype"):
+        ThomsonScatteringDiagnostic(cfg, sa)
