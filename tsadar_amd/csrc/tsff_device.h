@@ -35,6 +35,42 @@ constexpr int kNXi2 = TSFF_NXI2;
 constexpr int kNXi1 = TSFF_NXI1;
 
 // ------------------------------------------------------------------------------------------
+// fast float64 reciprocal / square root for operands in the normal range (no denormal or
+// overflow rescaling, which the library forms spend ~40 % of their instructions on): the hardware
+// seed (v_rcp_f64 / v_rsq_f64) plus two Newton / Goldschmidt steps, ~1 ulp.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double frcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+
+// s = sqrt(x), is = 1/sqrt(x)
+__device__ __forceinline__ void fsqrt2(double x, double& s, double& is) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  s = __builtin_fma(d, h, g);
+  is = h + h;
+}
+
+// A value every lane of the wavefront holds identically (lineout scalars, per-angle constants):
+// move it to SGPRs so it stops occupying a VGPR pair in every lane.
+__device__ __forceinline__ double uni(double x) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------
 // wavefront / workgroup reductions (64-wide wavefronts, xor-shuffle butterflies)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -95,8 +131,8 @@ __device__ __forceinline__ void zprime_lookup(const double2* zp, double xi, doub
   const double2 a = zp[i], b = zp[i + 1];
   const double dr = b.x - a.x, di = b.y - a.y;
   if (xi < kXi2_0 || xi > xlast) {
-    const double i2 = 1.0 / (xi * xi);
-    zr = i2; zi = 0.0; dzr = -2.0 * i2 / xi; dzi = 0.0;
+    const double i2 = frcp(xi * xi);
+    zr = i2; zi = 0.0; dzr = -2.0 * i2 * i2 * xi; dzi = 0.0;
   } else {
     zr = a.x + t * dr; zi = a.y + t * di; dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
   }
@@ -146,6 +182,7 @@ struct Phys {  // physical parameters of one lineout (after ThomsonParams.__call
 template <int NI>
 struct LineS {
   double wpe2, wL, kL, ivTe, a_e, pref, Ud, Vd;
+  double i2wL;  // 2 / wL (derived; carries no adjoint of its own)
   double ixi[NI], a_i[NI], cs[NI];
 };
 
@@ -160,6 +197,7 @@ __device__ __forceinline__ void make_lines(const Phys<NI>& p, double lam_shift, 
   const double ne_g = 1.0e20 * p.ne * (1.0 + p.neg * cg);
   const double Te_g = p.Te * (1.0 + p.teg * cg);
   L.wL = kOmgLnum / (p.lam + lam_shift);
+  L.i2wL = 2.0 / L.wL;
   L.wpe2 = kC0sq * ne_g;
   L.kL = sqrt(L.wL * L.wL - L.wpe2) / kC;
   L.ivTe = 1.0 / sqrt(Te_g / kMe);
@@ -178,6 +216,16 @@ __device__ __forceinline__ void make_lines(const Phys<NI>& p, double lam_shift, 
     L.a_i[s] = kC0sq * kMe * p.Z[s] * p.Z[s] * p.fr[s] * ne_g / (Zbar * p.Ti[s]);
     L.cs[s] = p.fr[s] * p.Z[s] * p.Z[s] / (Zbar * vTi);
   }
+}
+
+// the lineout scalars are identical in every lane: keep them in SGPRs
+template <int NI>
+__device__ __forceinline__ void make_lines_uniform(const Phys<NI>& p, double lam_shift, int g, int G, LineS<NI>& L) {
+  make_lines<NI>(p, lam_shift, g, G, L);
+  L.wpe2 = uni(L.wpe2); L.wL = uni(L.wL); L.i2wL = uni(L.i2wL); L.kL = uni(L.kL); L.ivTe = uni(L.ivTe);
+  L.a_e = uni(L.a_e); L.pref = uni(L.pref); L.Ud = uni(L.Ud); L.Vd = uni(L.Vd);
+#pragma unroll
+  for (int s = 0; s < NI; ++s) { L.ixi[s] = uni(L.ixi[s]); L.a_i[s] = uni(L.a_i[s]); L.cs[s] = uni(L.cs[s]); }
 }
 
 // adjoint of make_lines: LB holds dL/d(LineS fields) summed over the points of gradient point g;
@@ -247,16 +295,24 @@ __device__ __forceinline__ void make_lines_adjoint(const Phys<NI>& p, double lam
 // per-point physics
 // ------------------------------------------------------------------------------------------
 struct Base {  // quantities needed at point j AND as the right neighbour of point j-1
-  double ks, k2, k, ik, wd, vph, xe, F, dH;
+  double ks, iks, k2, k, ik, wd, vph, xe, F, dH;
 };
 
+// k_s = sqrt(w_s^2 - wpe^2)/c and its reciprocal (form_factor.py:218; angle independent)
+__device__ __forceinline__ void ks_eval(double ws, double wpe2, double& ks, double& iks) {
+  double s, is;
+  fsqrt2(ws * ws - wpe2, s, is);
+  ks = s * (1.0 / kC);
+  iks = is * kC;
+}
+
 template <int NI>
-__device__ __forceinline__ void base_eval(double ws, double ks, double ct, const LineS<NI>& L, const Tables& T,
-                                          Base& b) {
-  b.ks = ks;                                               // form_factor.py:218 (angle independent, hoisted)
+__device__ __forceinline__ void base_eval(double ws, double ks, double iks, double ct, const LineS<NI>& L,
+                                          const Tables& T, Base& b) {
+  b.ks = ks;                                               // form_factor.py:218 (angle independent)
+  b.iks = iks;
   b.k2 = b.ks * b.ks + L.kL * L.kL - 2.0 * b.ks * L.kL * ct;  // :220
-  b.k = sqrt(b.k2);
-  b.ik = 1.0 / b.k;
+  fsqrt2(b.k2, b.k, b.ik);
   b.wd = (ws - L.wL) - b.k * L.Vd;                         // :216, 222-223
   b.vph = b.wd * b.ik;
   b.xe = b.vph * L.ivTe - L.Ud * L.ivTe;                   // :253
@@ -269,7 +325,7 @@ __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const
 template <int NI>
 __device__ __forceinline__ double point_forward(double ws, const Base& b, const Base& bn, bool has_next,
                                                 const LineS<NI>& L, const Tables& T) {
-  const double ik2 = 1.0 / b.k2;
+  const double ik2 = b.ik * b.ik;
   const double ike2 = L.a_e * ik2;
   double cre = 0.0, cim = 0.0, gsum = 0.0;
 #pragma unroll
@@ -284,15 +340,15 @@ __device__ __forceinline__ double point_forward(double ws, const Base& b, const 
   }
   double Wl, dW;
   w_lookup(T.W, b.xe, Wl, dW);
-  const double D = has_next ? (bn.F - b.F) / (bn.xe - b.xe) : 0.0;  // :258-259
+  const double D = has_next ? (bn.F - b.F) * frcp(bn.xe - b.xe) : 0.0;  // :258-259
   const double cer = -ike2 * Wl;                           // :270-271
   const double cei = kPi * ike2 * D;                       // :261
   const double er = 1.0 + cer + cre, ei = cei + cim;       // :274
   const double eps2 = er * er + ei * ei;
   const double ce2 = cer * cer + cei * cei;
   const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
-  const double S = (gsum * ce2 + ci2 * b.F * L.ivTe) * b.ik / eps2;  // :282-288
-  return S * (1.0 + 2.0 * b.wd / L.wL) * L.pref * ws * ws;           // :291-294
+  const double S = (gsum * ce2 + ci2 * b.F * L.ivTe) * b.ik * frcp(eps2);  // :282-288
+  return S * (1.0 + b.wd * L.i2wL) * L.pref * ws * ws;                     // :291-294
 }
 
 struct BaseAdj {  // adjoints flowing into base quantities of a point
@@ -306,7 +362,7 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
                                               const LineS<NI>& L, const Tables& T, double Pbar,
                                               BaseAdj& ba, double& xen, double& Fn, LineS<NI>& LB) {
   // ---- recompute forward ----
-  const double ik2 = 1.0 / b.k2;
+  const double ik2 = b.ik * b.ik;
   const double ike2 = L.a_e * ik2;
   double cre = 0.0, cim = 0.0, gsum = 0.0;
   double xi[NI], zr[NI], zi[NI], dzr[NI], dzi[NI], iki2[NI], gs[NI];
@@ -322,21 +378,22 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
   }
   double Wl, dW;
   w_lookup(T.W, b.xe, Wl, dW);
-  const double idx = has_next ? 1.0 / (bn.xe - b.xe) : 0.0;
+  const double idx = has_next ? frcp(bn.xe - b.xe) : 0.0;
   const double D = has_next ? (bn.F - b.F) * idx : 0.0;
   const double cer = -ike2 * Wl, cei = kPi * ike2 * D;
   const double er = 1.0 + cer + cre, ei = cei + cim;
-  const double eps2 = er * er + ei * ei, ieps2 = 1.0 / eps2;
+  const double eps2 = er * er + ei * ei, ieps2 = frcp(eps2);
   const double ce2 = cer * cer + cei * cei;
   const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
   const double N = gsum * ce2 + ci2 * b.F * L.ivTe;
   const double S = N * b.ik * ieps2;
-  const double dop = 1.0 + 2.0 * b.wd / L.wL;
+  const double dop = 1.0 + b.wd * L.i2wL;
   const double Q = L.pref * ws * ws;
   // ---- reverse ----
   const double Sb = Pbar * dop * Q;
-  ba.wd = Pbar * S * Q * 2.0 / L.wL;
-  LB.wL += Pbar * S * Q * (-2.0 * b.wd / (L.wL * L.wL));
+  const double PSQ = Pbar * S * Q;
+  ba.wd = PSQ * L.i2wL;
+  LB.wL -= PSQ * b.wd * (0.5 * L.i2wL * L.i2wL);
   LB.pref += Pbar * S * dop * ws * ws;
   const double Nb = Sb * b.ik * ieps2;
   ba.ik = Sb * N * ieps2;
@@ -394,12 +451,12 @@ __device__ __forceinline__ void base_reverse(double ct, const Base& b, const Lin
   const double k2b = ba.k2 + kb * 0.5 * b.ik;
   const double ksb = k2b * 2.0 * (b.ks - L.kL * ct);
   LB.kL += k2b * 2.0 * (L.kL - b.ks * ct);
-  LB.wpe2 += ksb * (-0.5 / (kC * kC * b.ks));
+  LB.wpe2 -= ksb * (0.5 / (kC * kC)) * b.iks;
 }
 
 template <int NI>
 __device__ __forceinline__ void zero_lines(LineS<NI>& L) {
-  L.wpe2 = L.wL = L.kL = L.ivTe = L.a_e = L.pref = L.Ud = L.Vd = 0.0;
+  L.wpe2 = L.wL = L.kL = L.ivTe = L.a_e = L.pref = L.Ud = L.Vd = L.i2wL = 0.0;
 #pragma unroll
   for (int s = 0; s < NI; ++s) L.ixi[s] = L.a_i[s] = L.cs[s] = 0.0;
 }

@@ -2,10 +2,10 @@
 //
 // Kernel map (reference rows are those of SURVEY.md section 8a; DESIGN.md section 4 has the details)
 //   k_fe_prepare   a2, a6(table part), a8 : f_e -> ln f_e Hermite table, ratmod, ratdf, W[1640] (ratintn)
-//   k_spectrum     a1, a4-a15            : one workgroup per (lineout, feature); forward sweep over
-//                                          (lambda x theta), IRF convolution, binning, normalisation,
-//                                          loss partials and -- MODE 1 -- the hand-written adjoint
-//   k_finalize     a1 (chain rule), a15  : per-lineout gradient w.r.t. the normalised leaves
+//   k_spectrum     a1, a4-a15            : one workgroup per lineout (256 threads per feature); forward sweep
+//                                          over (lambda x theta), IRF convolution, binning, normalisation,
+//                                          loss partials and -- MODE 1 -- the hand-written adjoint incl. the
+//                                          chain rule to the normalised leaves
 //   k_loss_reduce  a14                   : deterministic reduction of the masked loss sums
 //   k_form_factor  a4-a10                : raw FormFactor.__call__ output (known-answer tests)
 #include "tsff_device.h"
@@ -49,7 +49,6 @@ struct KCall {
   const double* data[2];
   double* thry[2];
   double* sqdev[2];
-  double* gpart;         // [B][2][NP]
   double* lpart;         // [B][3]
   double wts[3];
   int B;
@@ -162,45 +161,97 @@ __global__ __launch_bounds__(kThreads) void k_fe_prepare(KStatic S, const double
 // ------------------------------------------------------------------------------------------
 // shared helpers of the spectrum kernels
 // ------------------------------------------------------------------------------------------
+constexpr int kHalf = 256;  // threads per feature inside a k_spectrum workgroup (4 wavefronts)
+#ifndef TSFF_QUNROLL
+#define TSFF_QUNROLL 1  // unroll factor of the strip loop (points interleaved per thread)
+#endif
+#define TSFF_PRAGMA(x) _Pragma(#x)
+#define TSFF_UNROLL(n) TSFF_PRAGMA(unroll n)
+#ifndef TSFF_OCC
+#define TSFF_OCC 4  // wavefronts per SIMD the register allocator must leave room for (2 workgroups of 512 per CU)
+#endif
+
 struct Smem {
-  double2* zp;   // [1640]
-  double2* ht;   // [nvx]
-  double* W;     // [1640]
-  double* x;     // [npts]   model spectrum, later its adjoint
-  double* yb;    // [1024]   adjoint of the binned spectrum (MODE 1)
-  double* taps;  // [ntaps]
-  double* cosa;  // [n_angles]
-  double* wsa;   // [n_angles]
-  double* red;   // [4 * kNP_MAX + 16]
+  double2* zp;    // [1640]
+  double2* ht;    // [nvx]
+  double* W;      // [1640]
+  double* x[2];   // [npts]   model spectrum of each feature, later its adjoint
+  double* yb[2];  // [1024]   adjoint of the binned spectrum (MODE 1)
+  double* taps[2];
+  double* cosa;   // [n_angles]
+  double* wsa;    // [n_angles]
+  double* red;    // [8 * kNP_MAX + 64]
 };
 
-__device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int ntaps) {
+// LDS budget (in doubles) of one k_spectrum / k_form_factor workgroup
+__host__ __device__ inline size_t smem_doubles(const KStatic& S, int nfeat) {
+  return 2 * (size_t)(kNXi2 + S.nvx) + kNXi2 + (size_t)nfeat * ((size_t)S.npts + TSFF_NBINS) + S.ntaps[0] + S.ntaps[1] +
+         2 * (size_t)S.n_angles + 10 * kNP_MAX + 64;
+}
+
+__device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int nfeat) {
   Smem m;
   m.zp = reinterpret_cast<double2*>(smem);
   m.ht = m.zp + kNXi2;
   m.W = reinterpret_cast<double*>(m.ht + S.nvx);
-  m.x = m.W + kNXi2;
-  m.yb = m.x + S.npts;
-  m.taps = m.yb + TSFF_NBINS;
-  m.cosa = m.taps + ntaps;
-  m.wsa = m.cosa + S.n_angles;
-  m.red = m.wsa + S.n_angles;
+  double* p = m.W + kNXi2;
+  m.x[0] = p; p += S.npts;
+  m.x[1] = p; if (nfeat > 1) p += S.npts;
+  m.yb[0] = p; p += TSFF_NBINS;
+  m.yb[1] = p; if (nfeat > 1) p += TSFF_NBINS;
+  m.taps[0] = p; p += S.ntaps[0];
+  m.taps[1] = p; p += S.ntaps[1];
+  m.cosa = p; p += S.n_angles;
+  m.wsa = p; p += S.n_angles;
+  m.red = p;
   return m;
 }
 
-__device__ __forceinline__ void load_tables(const Smem& m, const KStatic& S, const KCall& K, int slot, int f,
+__device__ __forceinline__ void load_tables(const Smem& m, const KStatic& S, const KCall& K, int slot, bool with_taps,
                                             Tables& T) {
-  const int tid = threadIdx.x;
-  for (int i = tid; i < kNXi2; i += kThreads) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int i = tid; i < kNXi2; i += nthr) {
     m.zp[i] = S.zp[i];
     m.W[i] = K.W[(size_t)slot * kNXi2 + i];
   }
-  for (int i = tid; i < S.nvx; i += kThreads) m.ht[i] = K.ht[(size_t)slot * S.nvx + i];
-  if (f >= 0)
-    for (int i = tid; i < S.ntaps[f]; i += kThreads) m.taps[i] = S.taps[f][i];
-  for (int i = tid; i < S.n_angles; i += kThreads) { m.cosa[i] = S.cos_sa[i]; m.wsa[i] = S.w_sa[i]; }
+  for (int i = tid; i < S.nvx; i += nthr) m.ht[i] = K.ht[(size_t)slot * S.nvx + i];
+  if (with_taps) {
+    for (int i = tid; i < S.ntaps[0]; i += nthr) m.taps[0][i] = S.taps[0][i];
+    for (int i = tid; i < S.ntaps[1]; i += nthr) m.taps[1][i] = S.taps[1][i];
+  }
+  for (int i = tid; i < S.n_angles; i += nthr) { m.cosa[i] = S.cos_sa[i]; m.wsa[i] = S.w_sa[i]; }
   T.zp = m.zp; T.W = m.W; T.ht = m.ht; T.nvx = S.nvx;
   T.vx0 = S.vx0; T.dv = S.dv; T.idv = 1.0 / S.dv; T.vxlast = S.vx0 + (S.nvx - 1) * S.dv;
+}
+
+// reductions over the 4 wavefronts of one feature half; every thread of the WORKGROUP must call them
+// (they contain workgroup barriers).  scratch: 16 doubles.
+__device__ __forceinline__ double half_sum(double v, double* scratch, int half, int hw, int lane) {
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) scratch[half * 4 + hw] = v;
+  __syncthreads();
+  const double* r = scratch + half * 4;
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+__device__ __forceinline__ void half_argmax(double& v, int& idx, double* scratch, int half, int hw, int lane) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  __syncthreads();
+  if (lane == 0) { scratch[half * 8 + hw] = v; scratch[half * 8 + 4 + hw] = (double)idx; }
+  __syncthreads();
+  const double* r = scratch + half * 8;
+  v = r[0]; idx = (int)r[4];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const double ov = r[k]; const int oi = (int)r[4 + k];
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
 }
 
 // loss functional e(d, t) and de/dt (loss_function.py:386-418); the 1/uncert of l1/l2 is folded
@@ -214,103 +265,117 @@ __device__ __forceinline__ void loss_point(int method, double d, double t, doubl
 }
 
 // ------------------------------------------------------------------------------------------
-// k_spectrum: one workgroup per (lineout b, feature f).
-//   MODE 0: ThryE/ThryI                       (ThomsonScatteringDiagnostic.__call__)
-//   MODE 1: + masked loss sums + adjoint       (LossFunction.vg_loss)
+// k_spectrum: one workgroup per lineout; threads [0,256) evaluate the first loaded feature, threads
+// [256,512) the second (EPW, IAW), sharing the LDS copies of the Z', W and ln f_e tables.  A deck with
+// one feature launches 256-thread workgroups.
+//   MODE 0: ThryE/ThryI                              (ThomsonScatteringDiagnostic.__call__)
+//   MODE 1: + masked loss sums + adjoint -> grad      (LossFunction.vg_loss)
 //   MODE 2: + per-lineout sums, theory denominator, sqdev arrays (LossFunction.array_loss)
 // ------------------------------------------------------------------------------------------
 template <int NI, int MODE>
-__global__ __launch_bounds__(kThreads) void k_spectrum(KStatic S, KCall K) {
-  const int b = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
-  if (!S.load[f]) return;
+__global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCall K, int f0, int nfeat,
+                                                           const uint8_t* __restrict__ gmask, double* __restrict__ grad) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int half = tid >> 8, ht = tid & (kHalf - 1), lane = tid & 63, hw = (tid >> 6) & 3;
+  const int f = f0 + half;  // feature of this half (wavefront-uniform)
   extern __shared__ __align__(16) unsigned char smem[];
-  const int ntmax = S.ntaps[0] > S.ntaps[1] ? S.ntaps[0] : S.ntaps[1];
-  const Smem m = carve(smem, S, ntmax);
+  const Smem m = carve(smem, S, nfeat);
   Tables T;
-  load_tables(m, S, K, S.shared_fe ? 0 : b, f, T);
+  load_tables(m, S, K, S.shared_fe ? 0 : b, true, T);
 
-  Phys<NI> p;
-  load_phys<NI>(K.params + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+  const double* __restrict__ xpar = K.params + (size_t)b * S.NP;
   const double lam_shift = S.lam_shift[f];
   const double* __restrict__ omgs = S.omgs[f];
   const int npts = S.npts, ppp = S.ppp, G = S.G, NA = S.n_angles;
   const double invG = 1.0 / (double)G;
+  // (pointer arithmetic on the LDS base, not a runtime-indexed pointer array: keeps ds_* addressing)
+  double* __restrict__ xs = m.x[0] + (nfeat > 1 ? half * S.npts : 0);
+  for (int i = ht; i < npts; i += kHalf) xs[i] = 0.0;
   __syncthreads();
 
   // ================= forward sweep over (lambda strip, gradient point, angle) =================
+  // each thread owns strips of kStrip consecutive samples; the right neighbour's (xi_e, F) needed by the
+  // finite difference along lambda (form_factor.py:258) is evaluated by the owner of the strip.
   for (int c = 0; c < ppp; ++c) {
-    const int j0 = kStrip * (tid + kThreads * c);
-    double ws[kStrip + 1];
-#pragma unroll
-    for (int q = 0; q <= kStrip; ++q) ws[q] = omgs[min(j0 + q, npts - 1)];
-    double xacc[kStrip];
-#pragma unroll
-    for (int q = 0; q < kStrip; ++q) xacc[q] = 0.0;
+    const int j0 = kStrip * (ht + kHalf * c);
     for (int g = 0; g < G; ++g) {
       LineS<NI> L;
-      make_lines<NI>(p, lam_shift, g, G, L);
-      double ksv[kStrip + 1];
-#pragma unroll
-      for (int q = 0; q <= kStrip; ++q) ksv[q] = sqrt(ws[q] * ws[q] - L.wpe2) / kC;
+      {
+        Phys<NI> p;  // reloaded where needed instead of being kept live across the sweeps
+        load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+        make_lines_uniform<NI>(p, lam_shift, g, G, L);
+      }
       for (int a = 0; a < NA; ++a) {
-        const double ct = m.cosa[a], wa = m.wsa[a];
+        const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a] * invG);
+        double ws = omgs[j0], ks, iks;
+        ks_eval(ws, L.wpe2, ks, iks);
         Base b0;
-        base_eval<NI>(ws[0], ksv[0], ct, L, T, b0);
-#pragma unroll
+        base_eval<NI>(ws, ks, iks, ct, L, T, b0);
+        TSFF_UNROLL(TSFF_QUNROLL)
         for (int q = 0; q < kStrip; ++q) {
-          const bool has_next = (j0 + q + 1) < npts;
+          const int j = j0 + q;
+          const bool has_next = (j + 1) < npts;
+          const double wsn = omgs[min(j + 1, npts - 1)];
+          ks_eval(wsn, L.wpe2, ks, iks);
           Base b1;
-          base_eval<NI>(ws[q + 1], ksv[q + 1], ct, L, T, b1);
-          xacc[q] += wa * point_forward<NI>(ws[q], b0, b1, has_next, L, T);
+          base_eval<NI>(wsn, ks, iks, ct, L, T, b1);
+          xs[j] += wa * point_forward<NI>(ws, b0, b1, has_next, L, T);
           b0 = b1;
+          ws = wsn;
         }
       }
     }
-#pragma unroll
-    for (int q = 0; q < kStrip; ++q) {
-      const int j = j0 + q;
-      double v = xacc[q] * invG;
-      if (f == TSFF_FEATURE_ELE && S.filt) v *= S.filt[j];
-      m.x[j] = v;
-    }
   }
+  if (f == TSFF_FEATURE_ELE && S.filt)
+    for (int c = 0; c < ppp; ++c) {
+      const int j0 = kStrip * (ht + kHalf * c);
+#pragma unroll
+      for (int q = 0; q < kStrip; ++q) xs[j0 + q] *= S.filt[j0 + q];
+    }
   __syncthreads();
 
   // ================= IRF convolution ("same"), bin average, normalisation =================
   const int nt = S.ntaps[f], dmin = S.dmin[f], dmax = dmin + nt - 1;
+  const double* __restrict__ taps = m.taps[0] + (f == TSFF_FEATURE_ELE ? 0 : S.ntaps[0]);
   const double invp = 1.0 / (double)ppp;
   double ybin[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int pb = tid + kThreads * r;
+    const int pb = ht + kHalf * r;
     double acc = 0.0;
     for (int jj = 0; jj < ppp; ++jj) {
       const int j = pb * ppp + jj;
       const int ilo = max(0, j - dmax), ihi = min(npts - 1, j - dmin);
       double s = 0.0;
-      for (int i = ilo; i <= ihi; ++i) s += m.taps[j - i - dmin] * m.x[i];
+      for (int i = ilo; i <= ihi; ++i) s += taps[j - i - dmin] * xs[i];
       acc += s;
     }
     ybin[r] = acc * invp;
   }
   double M = ybin[0];
-  int pstar = tid;
+  int pstar = ht;
 #pragma unroll
   for (int r = 1; r < 4; ++r)
-    if (ybin[r] > M) { M = ybin[r]; pstar = tid + kThreads * r; }
-  block_argmax(M, pstar, m.red);
+    if (ybin[r] > M) { M = ybin[r]; pstar = ht + kHalf * r; }
+  half_argmax(M, pstar, m.red, half, hw, lane);
   const double invM = 1.0 / M;
   const double amps = K.amps[f][b];
+  double p_lam, p_amp1, p_amp2, p_amp3;
+  {
+    Phys<NI> p;
+    load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+    p_lam = uni(p.lam); p_amp1 = uni(p.amp1); p_amp2 = uni(p.amp2); p_amp3 = uni(p.amp3);
+  }
   const double* __restrict__ lamb = S.lam_bin[f];
-  double Tb[4];   // dLoss/dT (MODE 1)
-  double Ap[4];   // amplitude factor of bin p
+  double Tb[4];  // dLoss/dT (MODE 1)
+  double Ap[4];  // amplitude factor of bin p
   double s0 = 0.0, s1 = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int pb = tid + kThreads * r;
+    const int pb = ht + kHalf * r;
     double A;
-    if (f == TSFF_FEATURE_ELE) A = amps * (lamb[pb] < p.lam ? p.amp1 : p.amp2);  // irf.py:126-130
-    else A = amps * p.amp3;                                                      // irf.py:76
+    if (f == TSFF_FEATURE_ELE) A = amps * (lamb[pb] < p_lam ? p_amp1 : p_amp2);  // irf.py:126-130
+    else A = amps * p_amp3;                                                      // irf.py:76
     Ap[r] = A;
     double t = A * ybin[r] * invM;
     if (K.noise[f]) t += K.noise[f][(size_t)b * TSFF_NBINS + pb];             // thomson_diagnostic.py:139-140
@@ -336,9 +401,9 @@ __global__ __launch_bounds__(kThreads) void k_spectrum(KStatic S, KCall K) {
     }
   }
   if (MODE == 0) return;
-  s0 = block_sum(s0, m.red);
-  s1 = block_sum(s1, m.red);
-  if (tid == 0) {
+  s0 = half_sum(s0, m.red, half, hw, lane);
+  s1 = half_sum(s1, m.red, half, hw, lane);
+  if (ht == 0) {
     if (f == TSFF_FEATURE_ELE) { K.lpart[(size_t)b * 3 + 1] = s0; K.lpart[(size_t)b * 3 + 2] = s1; }
     else K.lpart[(size_t)b * 3 + 0] = s0;
   }
@@ -349,146 +414,149 @@ __global__ __launch_bounds__(kThreads) void k_spectrum(KStatic S, KCall K) {
   double sn = 0.0, a1b = 0.0, a2b = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int pb = tid + kThreads * r;
+    const int pb = ht + kHalf * r;
     const double u = Tb[r] * ybin[r] * invM;  // dL/dA_p
     sn += u * Ap[r];
-    if (f == TSFF_FEATURE_ELE) { if (lamb[pb] < p.lam) a1b += u * amps; else a2b += u * amps; }
+    if (f == TSFF_FEATURE_ELE) { if (lamb[pb] < p_lam) a1b += u * amps; else a2b += u * amps; }
     else a1b += u * amps;
   }
-  sn = block_sum(sn, m.red);
-  a1b = block_sum(a1b, m.red);
-  a2b = block_sum(a2b, m.red);
+  sn = half_sum(sn, m.red, half, hw, lane);
+  a1b = half_sum(a1b, m.red, half, hw, lane);
+  a2b = half_sum(a2b, m.red, half, hw, lane);
+  double* __restrict__ ybs = m.yb[0] + (nfeat > 1 ? half * TSFF_NBINS : 0);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int pb = tid + kThreads * r;
+    const int pb = ht + kHalf * r;
     double yb = Tb[r] * Ap[r] * invM;
     if (pb == pstar) yb -= sn * invM;
-    m.yb[pb] = yb * invp;
+    ybs[pb] = yb * invp;
   }
   __syncthreads();
   // ================= adjoint of the convolution: xbar_i = filt_i * sum_j ybar_j g[j-i] =================
-  for (int i = tid; i < npts; i += kThreads) {
+  for (int i = ht; i < npts; i += kHalf) {
     const int jlo = max(0, i + dmin), jhi = min(npts - 1, i + dmax);
     double s = 0.0;
-    for (int j = jlo; j <= jhi; ++j) s += m.taps[j - i - dmin] * m.yb[j / ppp];
+    for (int j = jlo; j <= jhi; ++j) s += taps[j - i - dmin] * ybs[j / ppp];
     if (f == TSFF_FEATURE_ELE && S.filt) s *= S.filt[i];
-    m.x[i] = s * invG;
+    xs[i] = s * invG;
   }
   __syncthreads();
 
-  // ================= reverse sweep: recompute each point, accumulate parameter adjoints =================
+  // ================= reverse sweep: recompute each point, accumulate lineout-scalar adjoints =================
   constexpr int NPk = TSFF_NP(NI);
-  double pbar[NPk];
-#pragma unroll
-  for (int s = 0; s < NPk; ++s) pbar[s] = 0.0;
+  constexpr int NLB = 8 + 3 * NI;               // adjoint-carrying fields of LineS
+  double* gsum = m.red + 8 * kNP_MAX;           // [2][NPk] physical-parameter adjoints of the two features
+  if (ht < NPk) gsum[half * NPk + ht] = 0.0;
+  const int wv = tid >> 6;
   for (int g = 0; g < G; ++g) {
     LineS<NI> L, LB;
-    make_lines<NI>(p, lam_shift, g, G, L);
+    {
+      Phys<NI> p;
+      load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+      make_lines_uniform<NI>(p, lam_shift, g, G, L);
+    }
     zero_lines<NI>(LB);
     for (int c = 0; c < ppp; ++c) {
-      const int j0 = kStrip * (tid + kThreads * c);
-      double ws[kStrip + 1], ksv[kStrip + 1], xb[kStrip];
-#pragma unroll
-      for (int q = 0; q <= kStrip; ++q) {
-        ws[q] = omgs[min(j0 + q, npts - 1)];
-        ksv[q] = sqrt(ws[q] * ws[q] - L.wpe2) / kC;
-      }
-#pragma unroll
-      for (int q = 0; q < kStrip; ++q) xb[q] = m.x[j0 + q];
+      const int j0 = kStrip * (ht + kHalf * c);
       for (int a = 0; a < NA; ++a) {
-        const double ct = m.cosa[a], wa = m.wsa[a];
+        const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a]);
+        double ws = omgs[j0], ks, iks;
+        ks_eval(ws, L.wpe2, ks, iks);
         Base b0;
-        base_eval<NI>(ws[0], ksv[0], ct, L, T, b0);
+        base_eval<NI>(ws, ks, iks, ct, L, T, b0);
         double cxe = 0.0, cF = 0.0;
-        bool last_has_next = false;
-#pragma unroll
+        TSFF_UNROLL(TSFF_QUNROLL)
         for (int q = 0; q < kStrip; ++q) {
-          const bool has_next = (j0 + q + 1) < npts;
+          const int j = j0 + q;
+          const bool has_next = (j + 1) < npts;
+          const double wsn = omgs[min(j + 1, npts - 1)];
+          ks_eval(wsn, L.wpe2, ks, iks);
           Base b1;
-          base_eval<NI>(ws[q + 1], ksv[q + 1], ct, L, T, b1);
+          base_eval<NI>(wsn, ks, iks, ct, L, T, b1);
           BaseAdj ba;
           double xen, Fn;
-          point_reverse<NI>(ws[q], b0, b1, has_next, L, T, xb[q] * wa, ba, xen, Fn, LB);
+          point_reverse<NI>(ws, b0, b1, has_next, L, T, xs[j] * wa, ba, xen, Fn, LB);
           ba.xe += cxe; ba.F += cF;
           base_reverse<NI>(ct, b0, L, ba, LB);
           cxe = xen; cF = Fn;
           b0 = b1;
-          last_has_next = has_next;
+          ws = wsn;
         }
-        if (last_has_next) {  // the strip's right neighbour receives the D-coupling of the last point
+        if (j0 + kStrip < npts) {  // the strip's right neighbour receives the D-coupling of the last point
           BaseAdj ba;
           ba.k2 = ba.ik = ba.wd = ba.vph = 0.0; ba.xe = cxe; ba.F = cF;
           base_reverse<NI>(ct, b0, L, ba, LB);
         }
       }
     }
-    make_lines_adjoint<NI>(p, lam_shift, g, G, L, LB, pbar);
+    // ---- reduce the lineout-scalar adjoints over the feature's 4 wavefronts; one thread per feature
+    //      chains them to the physical parameters (make_lines_adjoint) ----
+    {
+      double lb[NLB];
+      lb[0] = LB.wpe2; lb[1] = LB.wL; lb[2] = LB.kL; lb[3] = LB.ivTe; lb[4] = LB.a_e; lb[5] = LB.pref; lb[6] = LB.Ud; lb[7] = LB.Vd;
+#pragma unroll
+      for (int s = 0; s < NI; ++s) { lb[8 + 3 * s] = LB.ixi[s]; lb[9 + 3 * s] = LB.a_i[s]; lb[10 + 3 * s] = LB.cs[s]; }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NLB; ++k) {
+        const double v = wave_sum(lb[k]);
+        if (lane == 0) m.red[wv * NLB + k] = v;
+      }
+      __syncthreads();
+      if (ht == 0) {
+        const double* r = m.red + (half * 4) * NLB;
+#pragma unroll
+        for (int k = 0; k < NLB; ++k) lb[k] = (r[k] + r[NLB + k]) + (r[2 * NLB + k] + r[3 * NLB + k]);
+        LB.wpe2 = lb[0]; LB.wL = lb[1]; LB.kL = lb[2]; LB.ivTe = lb[3]; LB.a_e = lb[4]; LB.pref = lb[5]; LB.Ud = lb[6]; LB.Vd = lb[7];
+#pragma unroll
+        for (int s = 0; s < NI; ++s) { LB.ixi[s] = lb[8 + 3 * s]; LB.a_i[s] = lb[9 + 3 * s]; LB.cs[s] = lb[10 + 3 * s]; }
+        Phys<NI> p;
+        load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+        double pbar[NPk];
+#pragma unroll
+        for (int s = 0; s < NPk; ++s) pbar[s] = 0.0;
+        make_lines_adjoint<NI>(p, lam_shift, g, G, L, LB, pbar);
+#pragma unroll
+        for (int s = 0; s < NPk; ++s) gsum[half * NPk + s] += pbar[s];
+      }
+    }
   }
   // amplitudes (irf.py:76,126-130)
-  if (f == TSFF_FEATURE_ELE) {
-    if (tid == 0) { pbar[TSFF_P_AMP1] += a1b; pbar[TSFF_P_AMP2] += a2b; }
-  } else {
-    if (tid == 0) pbar[TSFF_P_AMP3] += a1b;
-  }
-  // workgroup reduction of the parameter adjoints -> gpart[b][f][:]
-  const int lane = tid & 63, wave = tid >> 6;
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < NPk; ++s) {
-    const double v = wave_sum(pbar[s]);
-    if (lane == 0) m.red[wave * NPk + s] = v;
+  if (ht == 0) {
+    if (f == TSFF_FEATURE_ELE) { gsum[half * NPk + TSFF_P_AMP1] += a1b; gsum[half * NPk + TSFF_P_AMP2] += a2b; }
+    else gsum[half * NPk + TSFF_P_AMP3] += a1b;
   }
   __syncthreads();
-  if (tid < NPk)
-    K.gpart[((size_t)b * 2 + f) * S.NP + tid] =
-        (m.red[tid] + m.red[NPk + tid]) + (m.red[2 * NPk + tid] + m.red[3 * NPk + tid]);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_finalize: gradient w.r.t. the normalised leaves.  One thread per lineout.
-// chain: feature sum -> Ti tying -> fraction renormalisation -> activation * scale
-// (ts_params.py:329-350, 543-563)
-// ------------------------------------------------------------------------------------------
-template <int NI>
-__global__ void k_finalize(KStatic S, const double* __restrict__ params, const double* __restrict__ gpart,
-                           const uint8_t* __restrict__ gmask, double* __restrict__ grad, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  constexpr int NPk = TSFF_NP(NI);
-  double g[NPk];
+  // ---- feature sum and the chain rule to the normalised leaves (Ti tying, fraction renormalisation,
+  //      activation; ts_params.py:329-350, 543-563) ----
+  if (tid == 0) {
+    if (nfeat > 1)
+      for (int s = 0; s < NPk; ++s) gsum[s] += gsum[NPk + s];
+    Phys<NI> p;
+    load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
 #pragma unroll
-  for (int s = 0; s < NPk; ++s) {
-    double v = 0.0;
-    if (S.load[0]) v += gpart[((size_t)b * 2 + 0) * NPk + s];
-    if (S.load[1]) v += gpart[((size_t)b * 2 + 1) * NPk + s];
-    g[s] = v;
-  }
-  const double* x = params + (size_t)b * NPk;
-  Phys<NI> p;
-  load_phys<NI>(x, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
-  // Ti tying
+    for (int s = 1; s < NI; ++s)
+      if (S.ti_same[s]) {
+        gsum[TSFF_P_ION0 + TSFF_ION_TI] += gsum[TSFF_P_ION0 + 4 * s + TSFF_ION_TI];
+        gsum[TSFF_P_ION0 + 4 * s + TSFF_ION_TI] = 0.0;
+      }
+    double dot = 0.0;
 #pragma unroll
-  for (int s = 1; s < NI; ++s)
-    if (S.ti_same[s]) {
-      g[TSFF_P_ION0 + TSFF_ION_TI] += g[TSFF_P_ION0 + 4 * s + TSFF_ION_TI];
-      g[TSFF_P_ION0 + 4 * s + TSFF_ION_TI] = 0.0;
+    for (int s = 0; s < NI; ++s) dot += gsum[TSFF_P_ION0 + 4 * s + TSFF_ION_FRACT] * p.fr[s];
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+      const int o = TSFF_P_ION0 + 4 * s + TSFF_ION_FRACT;
+      gsum[o] = (gsum[o] - dot) / p.fsum;
+      gsum[TSFF_P_ION0 + 4 * s + TSFF_ION_A] = 0.0;
     }
-  // fract_s = f_s / sum(f)
-  double dot = 0.0;
-#pragma unroll
-  for (int s = 0; s < NI; ++s) dot += g[TSFF_P_ION0 + 4 * s + TSFF_ION_FRACT] * p.fr[s];
-#pragma unroll
-  for (int s = 0; s < NI; ++s) {
-    const int o = TSFF_P_ION0 + 4 * s + TSFF_ION_FRACT;
-    g[o] = (g[o] - dot) / p.fsum;
-    g[TSFF_P_ION0 + 4 * s + TSFF_ION_A] = 0.0;
+    gsum[TSFF_P_M] = 0.0;
   }
-  g[TSFF_P_M] = 0.0;
-#pragma unroll
-  for (int s = 0; s < NPk; ++s) {
-    double v = g[s] * S.p_scale[s];
-    if (S.p_sig[s]) { const double sg = sigmoid(x[s]); v *= sg * (1.0 - sg); }
-    grad[(size_t)b * NPk + s] = gmask[s] ? v : 0.0;
+  __syncthreads();
+  if (tid < NPk) {
+    const double xv = xpar[tid];
+    double v = gsum[tid] * S.p_scale[tid];
+    if (S.p_sig[tid]) { const double sg = sigmoid(xv); v *= sg * (1.0 - sg); }
+    grad[(size_t)b * NPk + tid] = gmask[tid] ? v : 0.0;
   }
 }
 
@@ -514,9 +582,9 @@ __global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, in
                                                           int npts, double* __restrict__ P) {
   const int b = blockIdx.x, tid = threadIdx.x;
   extern __shared__ __align__(16) unsigned char smem[];
-  const Smem m = carve(smem, S, 0);
+  const Smem m = carve(smem, S, 1);
   Tables T;
-  load_tables(m, S, K, S.shared_fe ? 0 : b, -1, T);
+  load_tables(m, S, K, S.shared_fe ? 0 : b, false, T);
   Phys<NI> p;
   load_phys<NI>(K.params + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, false, p);
   __syncthreads();
@@ -530,19 +598,19 @@ __global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, in
     for (int g = 0; g < G; ++g) {
       LineS<NI> L;
       make_lines<NI>(p, S.lam_shift[f], g, G, L);
-      double ksv[kStrip + 1];
+      double ksv[kStrip + 1], iksv[kStrip + 1];
 #pragma unroll
-      for (int q = 0; q <= kStrip; ++q) ksv[q] = sqrt(ws[q] * ws[q] - L.wpe2) / kC;
+      for (int q = 0; q <= kStrip; ++q) ks_eval(ws[q], L.wpe2, ksv[q], iksv[q]);
       for (int a = 0; a < NA; ++a) {
         const double ct = m.cosa[a];
         Base b0;
-        base_eval<NI>(ws[0], ksv[0], ct, L, T, b0);
+        base_eval<NI>(ws[0], ksv[0], iksv[0], ct, L, T, b0);
 #pragma unroll
         for (int q = 0; q < kStrip; ++q) {
           const int j = j0 + q;
           const bool has_next = (j + 1) < npts;
           Base b1;
-          base_eval<NI>(ws[q + 1], ksv[q + 1], ct, L, T, b1);
+          base_eval<NI>(ws[q + 1], ksv[q + 1], iksv[q + 1], ct, L, T, b1);
           if (j < npts) P[(((size_t)b * G + g) * npts + j) * NA + a] = point_forward<NI>(ws[q], b0, b1, has_next, L, T);
           b0 = b1;
         }
