@@ -294,31 +294,97 @@ __device__ __forceinline__ void make_lines_adjoint(const Phys<NI>& p, double lam
 // ------------------------------------------------------------------------------------------
 // per-point physics
 // ------------------------------------------------------------------------------------------
+
+// exp(x) for x <= ~1 (arguments here are ln f_e in [-50, 2] and -xi_i^2 <= 0): Cody-Waite reduction by
+// ln 2 and a degree-13 Taylor polynomial on |r| <= ln2/2 (truncation 4e-18); no overflow handling,
+// underflow to 0 through v_ldexp_f64.  ~1 ulp, 19 instructions instead of the library's ~30.
+#ifndef TSFF_FEXP
+#define TSFF_FEXP 1
+#endif
+#ifndef TSFF_FASTPATH
+#define TSFF_FASTPATH 0  // wavefront-uniform ion fast paths: measured slower (extra control flow), kept for experiments
+#endif
+__device__ __forceinline__ double fexp(double x) {
+#if !TSFF_FEXP
+  return exp(x);
+#endif
+  x = fmax(x, -800.0);
+  const double n = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                 // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);     // 1/12!
+  p = __builtin_fma(p, r, 2.505210838544172e-08);    // 1/11!
+  p = __builtin_fma(p, r, 2.755731922398589e-07);    // 1/10!
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);   // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873e-05);     // 1/8!
+  p = __builtin_fma(p, r, 1.984126984126984e-04);    // 1/7!
+  p = __builtin_fma(p, r, 1.388888888888889e-03);    // 1/6!
+  p = __builtin_fma(p, r, 8.333333333333333e-03);    // 1/5!
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);   // 1/4!
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);   // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
 struct Base {  // quantities needed at point j AND as the right neighbour of point j-1
-  double ks, iks, k2, k, ik, wd, vph, xe, F, dH;
+  double ks, k2, ik, wd, xe, F, dH;   // k = k2*ik, v_ph = wd*ik
 };
 
-// k_s = sqrt(w_s^2 - wpe^2)/c and its reciprocal (form_factor.py:218; angle independent)
-__device__ __forceinline__ void ks_eval(double ws, double wpe2, double& ks, double& iks) {
+// k_s = sqrt(w_s^2 - wpe^2)/c (form_factor.py:218; angle independent)
+__device__ __forceinline__ double ks_eval(double ws, double wpe2) {
   double s, is;
   fsqrt2(ws * ws - wpe2, s, is);
-  ks = s * (1.0 / kC);
-  iks = is * kC;
+  return s * (1.0 / kC);
 }
 
 template <int NI>
-__device__ __forceinline__ void base_eval(double ws, double ks, double iks, double ct, const LineS<NI>& L,
-                                          const Tables& T, Base& b) {
-  b.ks = ks;                                               // form_factor.py:218 (angle independent)
-  b.iks = iks;
-  b.k2 = b.ks * b.ks + L.kL * L.kL - 2.0 * b.ks * L.kL * ct;  // :220
-  fsqrt2(b.k2, b.k, b.ik);
-  b.wd = (ws - L.wL) - b.k * L.Vd;                         // :216, 222-223
-  b.vph = b.wd * b.ik;
-  b.xe = b.vph * L.ivTe - L.Ud * L.ivTe;                   // :253
+__device__ __forceinline__ void base_eval(double ws, double ks, double ct, const LineS<NI>& L, const Tables& T,
+                                          Base& b) {
+  b.ks = ks;
+  b.k2 = ks * ks + L.kL * L.kL - 2.0 * ks * L.kL * ct;     // :220
+  double k;
+  fsqrt2(b.k2, k, b.ik);
+  b.wd = (ws - L.wL) - k * L.Vd;                           // :216, 222-223
+  b.xe = (b.wd * b.ik - L.Ud) * L.ivTe;                    // :253
   double H;
   hermite_lookup(T, b.xe, H, b.dH);
-  b.F = exp(H);                                            // :256
+  b.F = fexp(H);                                           // :256
+}
+
+// ion terms of one species at normalised phase velocity xi (form_factor.py:243-249, 277-280):
+// Z'(xi) with its slope and gs = exp(-xi^2)/sqrt(2 pi).  Two wavefront-uniform fast paths: the EPW
+// window is almost entirely beyond the Z' table and far enough for exp(-xi^2) to vanish (|xi| > 28:
+// exp(-784) = 0 in float64); the IAW window is almost entirely inside the table.
+__device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& zr, double& zi, double& dzr,
+                                          double& dzi, double& gs) {
+#if TSFF_FASTPATH
+  const double ax = fabs(xi);
+  if (__all(ax > 28.0)) {
+    const double i2 = frcp(xi * xi);
+    zr = i2; zi = 0.0; dzr = -2.0 * i2 * i2 * xi; dzi = 0.0; gs = 0.0;
+    return;
+  }
+#endif
+  gs = fexp(-xi * xi) * kInvSqrt2Pi;
+  const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
+  const double u = (xi - kXi2_0) * kXi2_ih;
+  int i = (int)u;
+  i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
+  const double t = (xi - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
+  const double2 a = zp[i], b = zp[i + 1];
+  const double dr = b.x - a.x, di = b.y - a.y;
+  zr = a.x + t * dr; zi = a.y + t * di; dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
+  const bool out = xi < kXi2_0 || xi > xlast;
+#if TSFF_FASTPATH
+  if (__any(out))
+#endif
+  {
+    const double i2 = frcp(xi * xi);
+    if (out) { zr = i2; zi = 0.0; dzr = -2.0 * i2 * i2 * xi; dzi = 0.0; }
+  }
 }
 
 // P(lambda_j, theta_a) of one gradient point (form_factor.py:247-296)
@@ -327,16 +393,17 @@ __device__ __forceinline__ double point_forward(double ws, const Base& b, const 
                                                 const LineS<NI>& L, const Tables& T) {
   const double ik2 = b.ik * b.ik;
   const double ike2 = L.a_e * ik2;
+  const double vph = b.wd * b.ik;
   double cre = 0.0, cim = 0.0, gsum = 0.0;
 #pragma unroll
   for (int s = 0; s < NI; ++s) {
-    const double xi = b.vph * L.ixi[s];                    // :243
-    double zr, zi, dzr, dzi;
-    zprime_lookup(T.zp, xi, zr, zi, dzr, dzi);
+    const double xi = vph * L.ixi[s];                      // :243
+    double zr, zi, dzr, dzi, gs;
+    ion_terms(T.zp, xi, zr, zi, dzr, dzi, gs);
     const double iki2 = L.a_i[s] * ik2;
     cre -= 0.5 * iki2 * zr;                                // :249
     cim -= 0.5 * iki2 * zi;
-    gsum += L.cs[s] * exp(-xi * xi) * kInvSqrt2Pi;         // :277-280
+    gsum += L.cs[s] * gs;                                  // :277-280
   }
   double Wl, dW;
   w_lookup(T.W, b.xe, Wl, dW);
@@ -352,7 +419,7 @@ __device__ __forceinline__ double point_forward(double ws, const Base& b, const 
 }
 
 struct BaseAdj {  // adjoints flowing into base quantities of a point
-  double k2, ik, wd, vph, xe, F;
+  double k2, ik, wd, xe, F;
 };
 
 // reverse of point_forward: given Pbar, produce adjoints of this point's base quantities (ba),
@@ -364,16 +431,16 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
   // ---- recompute forward ----
   const double ik2 = b.ik * b.ik;
   const double ike2 = L.a_e * ik2;
+  const double vph = b.wd * b.ik;
   double cre = 0.0, cim = 0.0, gsum = 0.0;
   double xi[NI], zr[NI], zi[NI], dzr[NI], dzi[NI], iki2[NI], gs[NI];
 #pragma unroll
   for (int s = 0; s < NI; ++s) {
-    xi[s] = b.vph * L.ixi[s];
-    zprime_lookup(T.zp, xi[s], zr[s], zi[s], dzr[s], dzi[s]);
+    xi[s] = vph * L.ixi[s];
+    ion_terms(T.zp, xi[s], zr[s], zi[s], dzr[s], dzi[s], gs[s]);
     iki2[s] = L.a_i[s] * ik2;
     cre -= 0.5 * iki2[s] * zr[s];
     cim -= 0.5 * iki2[s] * zi[s];
-    gs[s] = exp(-xi[s] * xi[s]) * kInvSqrt2Pi;
     gsum += L.cs[s] * gs[s];
   }
   double Wl, dW;
@@ -423,12 +490,14 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
     LB.a_i[s] += iki2b * ik2;
     k2b -= iki2b * iki2[s] * ik2;
     vphb += xib * L.ixi[s];
-    LB.ixi[s] += xib * b.vph;
+    LB.ixi[s] += xib * vph;
   }
   LB.a_e += ike2b * ik2;
   k2b -= ike2b * ike2 * ik2;
   ba.k2 = k2b;
-  ba.vph = vphb;
+  // v_ph = wd * ik
+  ba.wd += vphb * b.ik;
+  ba.ik += vphb * b.wd;
 }
 
 // reverse of base_eval
@@ -436,22 +505,23 @@ template <int NI>
 __device__ __forceinline__ void base_reverse(double ct, const Base& b, const LineS<NI>& L, const BaseAdj& ba,
                                              LineS<NI>& LB) {
   const double xeb = ba.xe + ba.F * b.F * b.dH;
+  const double vph = b.wd * b.ik, k = b.k2 * b.ik;
   // xe = (vph - Ud) * ivTe
-  const double vphb = ba.vph + xeb * L.ivTe;
-  LB.Ud -= xeb * L.ivTe;
-  LB.ivTe += xeb * (b.vph - L.Ud);
+  const double vphb = xeb * L.ivTe;
+  LB.Ud -= vphb;
+  LB.ivTe += xeb * (vph - L.Ud);
   // vph = wd * ik
   const double wdb = ba.wd + vphb * b.ik;
   const double ikb = ba.ik + vphb * b.wd;
   // wd = ws - wL - k Vd
   LB.wL -= wdb;
-  LB.Vd -= wdb * b.k;
-  double kb = -wdb * L.Vd;
-  kb -= ikb * b.ik * b.ik;
+  LB.Vd -= wdb * k;
+  // k = sqrt(k2), ik = 1/k
+  const double kb = -wdb * L.Vd - ikb * b.ik * b.ik;
   const double k2b = ba.k2 + kb * 0.5 * b.ik;
   const double ksb = k2b * 2.0 * (b.ks - L.kL * ct);
   LB.kL += k2b * 2.0 * (L.kL - b.ks * ct);
-  LB.wpe2 -= ksb * (0.5 / (kC * kC)) * b.iks;
+  LB.wpe2 -= ksb * (0.5 / (kC * kC)) * frcp(b.ks);
 }
 
 template <int NI>

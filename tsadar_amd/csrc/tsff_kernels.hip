@@ -30,6 +30,7 @@ struct KStatic {
   const double* taps[2];
   int ntaps[2];
   int dmin[2];
+  int halo;                  // zero padding on both sides of the LDS spectrum buffers (>= every |tap offset|)
   const uint8_t* mask[2];    // [1024]
   const double* p_scale;
   const double* p_shift;
@@ -168,7 +169,7 @@ constexpr int kHalf = 256;  // threads per feature inside a k_spectrum workgroup
 #define TSFF_PRAGMA(x) _Pragma(#x)
 #define TSFF_UNROLL(n) TSFF_PRAGMA(unroll n)
 #ifndef TSFF_OCC
-#define TSFF_OCC 4  // wavefronts per SIMD the register allocator must leave room for (2 workgroups of 512 per CU)
+#define TSFF_OCC 2  // wavefronts per SIMD the register allocator must leave room for (one 512-thread workgroup per CU)
 #endif
 
 struct Smem {
@@ -185,8 +186,8 @@ struct Smem {
 
 // LDS budget (in doubles) of one k_spectrum / k_form_factor workgroup
 __host__ __device__ inline size_t smem_doubles(const KStatic& S, int nfeat) {
-  return 2 * (size_t)(kNXi2 + S.nvx) + kNXi2 + (size_t)nfeat * ((size_t)S.npts + TSFF_NBINS) + S.ntaps[0] + S.ntaps[1] +
-         2 * (size_t)S.n_angles + 10 * kNP_MAX + 64;
+  return 2 * (size_t)(kNXi2 + S.nvx) + kNXi2 + (size_t)nfeat * ((size_t)S.npts + TSFF_NBINS + 4 * (size_t)S.halo) +
+         S.ntaps[0] + S.ntaps[1] + 2 * (size_t)S.n_angles + 10 * kNP_MAX + 64;
 }
 
 __device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int nfeat) {
@@ -195,10 +196,11 @@ __device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int
   m.ht = m.zp + kNXi2;
   m.W = reinterpret_cast<double*>(m.ht + S.nvx);
   double* p = m.W + kNXi2;
-  m.x[0] = p; p += S.npts;
-  m.x[1] = p; if (nfeat > 1) p += S.npts;
-  m.yb[0] = p; p += TSFF_NBINS;
-  m.yb[1] = p; if (nfeat > 1) p += TSFF_NBINS;
+  // x / yb buffers carry `halo` zeros on both sides so the convolutions need no bounds checks
+  m.x[0] = p; p += (size_t)nfeat * (S.npts + 2 * S.halo);
+  m.x[1] = nullptr;
+  m.yb[0] = p; p += (size_t)nfeat * (TSFF_NBINS + 2 * S.halo);
+  m.yb[1] = nullptr;
   m.taps[0] = p; p += S.ntaps[0];
   m.taps[1] = p; p += S.ntaps[1];
   m.cosa = p; p += S.n_angles;
@@ -289,8 +291,11 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   const int npts = S.npts, ppp = S.ppp, G = S.G, NA = S.n_angles;
   const double invG = 1.0 / (double)G;
   // (pointer arithmetic on the LDS base, not a runtime-indexed pointer array: keeps ds_* addressing)
-  double* __restrict__ xs = m.x[0] + (nfeat > 1 ? half * S.npts : 0);
-  for (int i = ht; i < npts; i += kHalf) xs[i] = 0.0;
+  const int H = S.halo;
+  double* __restrict__ xs = m.x[0] + half * (S.npts + 2 * H) + H;
+  double* __restrict__ ybs = m.yb[0] + half * (TSFF_NBINS + 2 * H) + H;
+  for (int i = ht - H; i < npts + H; i += kHalf) xs[i] = 0.0;
+  for (int i = ht - H; i < TSFF_NBINS + H; i += kHalf) ybs[i] = 0.0;
   __syncthreads();
 
   // ================= forward sweep over (lambda strip, gradient point, angle) =================
@@ -298,6 +303,9 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   // finite difference along lambda (form_factor.py:258) is evaluated by the owner of the strip.
   for (int c = 0; c < ppp; ++c) {
     const int j0 = kStrip * (ht + kHalf * c);
+    // the frequency axis is read from global memory (L1/L2): the strip's first two samples once per
+    // chunk, the others one iteration ahead of their use so the load latency hides behind a whole point
+    const double ws_first = omgs[j0], ws_second = omgs[min(j0 + 1, npts - 1)];
     for (int g = 0; g < G; ++g) {
       LineS<NI> L;
       {
@@ -307,18 +315,17 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       }
       for (int a = 0; a < NA; ++a) {
         const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a] * invG);
-        double ws = omgs[j0], ks, iks;
-        ks_eval(ws, L.wpe2, ks, iks);
+        double ws = ws_first, wnext = ws_second;
         Base b0;
-        base_eval<NI>(ws, ks, iks, ct, L, T, b0);
+        base_eval<NI>(ws, ks_eval(ws, L.wpe2), ct, L, T, b0);
         TSFF_UNROLL(TSFF_QUNROLL)
         for (int q = 0; q < kStrip; ++q) {
           const int j = j0 + q;
           const bool has_next = (j + 1) < npts;
-          const double wsn = omgs[min(j + 1, npts - 1)];
-          ks_eval(wsn, L.wpe2, ks, iks);
+          const double wsn = wnext;
+          wnext = omgs[min(j + 2, npts - 1)];
           Base b1;
-          base_eval<NI>(wsn, ks, iks, ct, L, T, b1);
+          base_eval<NI>(wsn, ks_eval(wsn, L.wpe2), ct, L, T, b1);
           xs[j] += wa * point_forward<NI>(ws, b0, b1, has_next, L, T);
           b0 = b1;
           ws = wsn;
@@ -338,19 +345,31 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   const int nt = S.ntaps[f], dmin = S.dmin[f], dmax = dmin + nt - 1;
   const double* __restrict__ taps = m.taps[0] + (f == TSFF_FEATURE_ELE ? 0 : S.ntaps[0]);
   const double invp = 1.0 / (double)ppp;
-  double ybin[4];
+  double ybin[4] = {0.0, 0.0, 0.0, 0.0};
+  {
+    // y[j] = sum_t g[t] x[j - dmin - t]; the zero halo makes every index valid
+    const double* __restrict__ xp = xs - dmin;
+    if (ppp == 1) {  // one tap read feeds the thread's four bins
+      const double* __restrict__ x0 = xp + ht;
+#pragma unroll 4
+      for (int t = 0; t < nt; ++t) {
+        const double g = taps[t];
+        ybin[0] += g * x0[-t];
+        ybin[1] += g * x0[kHalf - t];
+        ybin[2] += g * x0[2 * kHalf - t];
+        ybin[3] += g * x0[3 * kHalf - t];
+      }
+    } else {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int pb = ht + kHalf * r;
-    double acc = 0.0;
-    for (int jj = 0; jj < ppp; ++jj) {
-      const int j = pb * ppp + jj;
-      const int ilo = max(0, j - dmax), ihi = min(npts - 1, j - dmin);
-      double s = 0.0;
-      for (int i = ilo; i <= ihi; ++i) s += taps[j - i - dmin] * xs[i];
-      acc += s;
+      for (int r = 0; r < 4; ++r) {
+        const double* __restrict__ x0 = xp + (ht + kHalf * r) * ppp;
+        double acc = 0.0;
+        for (int jj = 0; jj < ppp; ++jj)
+#pragma unroll 4
+          for (int t = 0; t < nt; ++t) acc += taps[t] * x0[jj - t];
+        ybin[r] = acc * invp;
+      }
     }
-    ybin[r] = acc * invp;
   }
   double M = ybin[0];
   int pstar = ht;
@@ -423,7 +442,6 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   sn = half_sum(sn, m.red, half, hw, lane);
   a1b = half_sum(a1b, m.red, half, hw, lane);
   a2b = half_sum(a2b, m.red, half, hw, lane);
-  double* __restrict__ ybs = m.yb[0] + (nfeat > 1 ? half * TSFF_NBINS : 0);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int pb = ht + kHalf * r;
@@ -433,12 +451,32 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   }
   __syncthreads();
   // ================= adjoint of the convolution: xbar_i = filt_i * sum_j ybar_j g[j-i] =================
-  for (int i = ht; i < npts; i += kHalf) {
-    const int jlo = max(0, i + dmin), jhi = min(npts - 1, i + dmax);
-    double s = 0.0;
-    for (int j = jlo; j <= jhi; ++j) s += taps[j - i - dmin] * ybs[j / ppp];
-    if (f == TSFF_FEATURE_ELE && S.filt) s *= S.filt[i];
-    xs[i] = s * invG;
+  if (ppp == 1) {
+    double sx[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ y0 = ybs + dmin + ht;
+#pragma unroll 4
+    for (int t = 0; t < nt; ++t) {
+      const double g = taps[t];
+      sx[0] += g * y0[t];
+      sx[1] += g * y0[kHalf + t];
+      sx[2] += g * y0[2 * kHalf + t];
+      sx[3] += g * y0[3 * kHalf + t];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ht + kHalf * r;
+      double v = sx[r];
+      if (f == TSFF_FEATURE_ELE && S.filt) v *= S.filt[i];
+      xs[i] = v * invG;
+    }
+  } else {
+    for (int i = ht; i < npts; i += kHalf) {
+      const int jlo = max(0, i + dmin), jhi = min(npts - 1, i + dmax);
+      double sv = 0.0;
+      for (int j = jlo; j <= jhi; ++j) sv += taps[j - i - dmin] * ybs[j / ppp];
+      if (f == TSFF_FEATURE_ELE && S.filt) sv *= S.filt[i];
+      xs[i] = sv * invG;
+    }
   }
   __syncthreads();
 
@@ -458,21 +496,21 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     zero_lines<NI>(LB);
     for (int c = 0; c < ppp; ++c) {
       const int j0 = kStrip * (ht + kHalf * c);
+      const double ws_first = omgs[j0], ws_second = omgs[min(j0 + 1, npts - 1)];
       for (int a = 0; a < NA; ++a) {
         const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a]);
-        double ws = omgs[j0], ks, iks;
-        ks_eval(ws, L.wpe2, ks, iks);
+        double ws = ws_first, wnext = ws_second;
         Base b0;
-        base_eval<NI>(ws, ks, iks, ct, L, T, b0);
+        base_eval<NI>(ws, ks_eval(ws, L.wpe2), ct, L, T, b0);
         double cxe = 0.0, cF = 0.0;
         TSFF_UNROLL(TSFF_QUNROLL)
         for (int q = 0; q < kStrip; ++q) {
           const int j = j0 + q;
           const bool has_next = (j + 1) < npts;
-          const double wsn = omgs[min(j + 1, npts - 1)];
-          ks_eval(wsn, L.wpe2, ks, iks);
+          const double wsn = wnext;
+          wnext = omgs[min(j + 2, npts - 1)];
           Base b1;
-          base_eval<NI>(wsn, ks, iks, ct, L, T, b1);
+          base_eval<NI>(wsn, ks_eval(wsn, L.wpe2), ct, L, T, b1);
           BaseAdj ba;
           double xen, Fn;
           point_reverse<NI>(ws, b0, b1, has_next, L, T, xs[j] * wa, ba, xen, Fn, LB);
@@ -484,7 +522,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
         }
         if (j0 + kStrip < npts) {  // the strip's right neighbour receives the D-coupling of the last point
           BaseAdj ba;
-          ba.k2 = ba.ik = ba.wd = ba.vph = 0.0; ba.xe = cxe; ba.F = cF;
+          ba.k2 = ba.ik = ba.wd = 0.0; ba.xe = cxe; ba.F = cF;
           base_reverse<NI>(ct, b0, L, ba, LB);
         }
       }
@@ -598,19 +636,19 @@ __global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, in
     for (int g = 0; g < G; ++g) {
       LineS<NI> L;
       make_lines<NI>(p, S.lam_shift[f], g, G, L);
-      double ksv[kStrip + 1], iksv[kStrip + 1];
+      double ksv[kStrip + 1];
 #pragma unroll
-      for (int q = 0; q <= kStrip; ++q) ks_eval(ws[q], L.wpe2, ksv[q], iksv[q]);
+      for (int q = 0; q <= kStrip; ++q) ksv[q] = ks_eval(ws[q], L.wpe2);
       for (int a = 0; a < NA; ++a) {
         const double ct = m.cosa[a];
         Base b0;
-        base_eval<NI>(ws[0], ksv[0], iksv[0], ct, L, T, b0);
+        base_eval<NI>(ws[0], ksv[0], ct, L, T, b0);
 #pragma unroll
         for (int q = 0; q < kStrip; ++q) {
           const int j = j0 + q;
           const bool has_next = (j + 1) < npts;
           Base b1;
-          base_eval<NI>(ws[q + 1], ksv[q + 1], iksv[q + 1], ct, L, T, b1);
+          base_eval<NI>(ws[q + 1], ksv[q + 1], ct, L, T, b1);
           if (j < npts) P[(((size_t)b * G + g) * npts + j) * NA + a] = point_forward<NI>(ws[q], b0, b1, has_next, L, T);
           b0 = b1;
         }
