@@ -115,7 +115,8 @@ __device__ __forceinline__ void block_argmax(double& v, int& idx, double* scratc
 struct Tables {
   const double2* zp;   // [1640] (Re Z', Im Z') on xi2
   const double* W;     // [1640] Re(chi_e) table on xi2
-  const double2* ht;   // [nvx]  (ln fe, node slope) on vx
+  const double2* ht;   // [nvx]  (ln fe, node slope) on vx            (k_fe_prepare)
+  const double2* hc;   // [2*(nvx-1)] cubic coefficients per interval: (f0, m0), (c2, c3)   (spectrum kernels)
   double vx0, dv, idv, vxlast;
   int nvx;
 };
@@ -149,6 +150,28 @@ __device__ __forceinline__ void w_lookup(const double* W, double xe, double& w, 
   if (xe < kXi2_0) { w = W[0]; dw = 0.0; }
   else if (xe > xlast) { w = W[kNXi2 - 1]; dw = 0.0; }
   else { w = a + t * (b - a); dw = (b - a) * kXi2_ih; }
+}
+
+// cubic coefficients of interval i of the Hermite interpolant in t = (x - vx_i)/dv:
+// H = f0 + t (m0 + t (c2 + t c3))
+__device__ __forceinline__ void hermite_coeffs(double2 a, double2 b, double dv, double2& c01, double2& c23) {
+  const double f0 = a.x, f1 = b.x, m0 = a.y * dv, m1 = b.y * dv;
+  c01 = make_double2(f0, m0);
+  c23 = make_double2(-3.0 * f0 + 3.0 * f1 - 2.0 * m0 - m1, 2.0 * f0 - 2.0 * f1 + m0 + m1);
+}
+
+// the same lookup as hermite_lookup() below from the per-interval coefficient table
+__device__ __forceinline__ void hermite_lookup_c(const Tables& T, double x, double& H, double& dH) {
+  const double u = (x - T.vx0) * T.idv;
+  int i = (int)u;
+  i = i < 0 ? 0 : (i > T.nvx - 2 ? T.nvx - 2 : i);
+  const double t = (x - (T.vx0 + i * T.dv)) * T.idv;
+  const double2 c01 = T.hc[2 * i], c23 = T.hc[2 * i + 1];
+  if (x < T.vx0 || x > T.vxlast) { H = -50.0; dH = 0.0; }
+  else {
+    H = c01.x + t * (c01.y + t * (c23.x + t * c23.y));
+    dH = (c01.y + t * (2.0 * c23.x + 3.0 * t * c23.y)) * T.idv;
+  }
 }
 
 // interpax.interp1d(x, vx, ln fe, method="cubic", extrap=[-50,-50])  (form_factor.py:256,263)
@@ -350,7 +373,7 @@ __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const
   b.wd = (ws - L.wL) - k * L.Vd;                           // :216, 222-223
   b.xe = (b.wd * b.ik - L.Ud) * L.ivTe;                    // :253
   double H;
-  hermite_lookup(T, b.xe, H, b.dH);
+  hermite_lookup_c(T, b.xe, H, b.dH);
   b.F = fexp(H);                                           // :256
 }
 
@@ -522,6 +545,21 @@ __device__ __forceinline__ void base_reverse(double ct, const Base& b, const Lin
   const double ksb = k2b * 2.0 * (b.ks - L.kL * ct);
   LB.kL += k2b * 2.0 * (L.kL - b.ks * ct);
   LB.wpe2 -= ksb * (0.5 / (kC * kC)) * frcp(b.ks);
+}
+
+// physical parameters staged once per workgroup in LDS: ph[slot] (after Ti tying and fraction
+// renormalisation), ph[NP] = sum of the un-normalised fractions
+template <int NI>
+__device__ __forceinline__ void phys_from_lds(const double* ph, Phys<NI>& p) {
+  p.Te = ph[TSFF_P_TE]; p.ne = ph[TSFF_P_NE]; p.m = ph[TSFF_P_M]; p.lam = ph[TSFF_P_LAM];
+  p.amp1 = ph[TSFF_P_AMP1]; p.amp2 = ph[TSFF_P_AMP2]; p.amp3 = ph[TSFF_P_AMP3];
+  p.neg = ph[TSFF_P_NE_GRADIENT]; p.teg = ph[TSFF_P_TE_GRADIENT]; p.ud = ph[TSFF_P_UD]; p.Va = ph[TSFF_P_VA];
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    const int o = TSFF_P_ION0 + 4 * s;
+    p.Ti[s] = ph[o + TSFF_ION_TI]; p.Z[s] = ph[o + TSFF_ION_Z]; p.A[s] = ph[o + TSFF_ION_A]; p.fr[s] = ph[o + TSFF_ION_FRACT];
+  }
+  p.fsum = ph[TSFF_NP(NI)];
 }
 
 template <int NI>

@@ -179,6 +179,9 @@ struct Smem {
   double* x[2];   // [npts]   model spectrum of each feature, later its adjoint
   double* yb[2];  // [1024]   adjoint of the binned spectrum (MODE 1)
   double* taps[2];
+  double2* hc;    // [2*(nvx-1)] Hermite coefficients per interval
+  double* ksc;    // [nfeat][npts + 1] k_s cache of the current gradient point
+  double* phys;   // [kNP_MAX + 1] physical parameters of this lineout
   double* cosa;   // [n_angles]
   double* wsa;    // [n_angles]
   double* red;    // [8 * kNP_MAX + 64]
@@ -186,8 +189,8 @@ struct Smem {
 
 // LDS budget (in doubles) of one k_spectrum / k_form_factor workgroup
 __host__ __device__ inline size_t smem_doubles(const KStatic& S, int nfeat) {
-  return 2 * (size_t)(kNXi2 + S.nvx) + kNXi2 + (size_t)nfeat * ((size_t)S.npts + TSFF_NBINS + 4 * (size_t)S.halo) +
-         S.ntaps[0] + S.ntaps[1] + 2 * (size_t)S.n_angles + 10 * kNP_MAX + 64;
+  return 2 * (size_t)(kNXi2 + S.nvx) + kNXi2 + (size_t)nfeat * ((size_t)S.npts + 2 * (size_t)S.halo) + 4 * (size_t)S.nvx +
+         (size_t)nfeat * ((size_t)S.npts + 2) + S.ntaps[0] + S.ntaps[1] + 2 * (size_t)S.n_angles + 11 * kNP_MAX + 66;
 }
 
 __device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int nfeat) {
@@ -197,12 +200,17 @@ __device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int
   m.W = reinterpret_cast<double*>(m.ht + S.nvx);
   double* p = m.W + kNXi2;
   // x / yb buffers carry `halo` zeros on both sides so the convolutions need no bounds checks
+  // (one buffer per feature holds, in turn, the model spectrum x, the adjoint of the binned spectrum and
+  //  the adjoint of x)
   m.x[0] = p; p += (size_t)nfeat * (S.npts + 2 * S.halo);
   m.x[1] = nullptr;
-  m.yb[0] = p; p += (size_t)nfeat * (TSFF_NBINS + 2 * S.halo);
+  m.yb[0] = nullptr;
   m.yb[1] = nullptr;
+  m.hc = reinterpret_cast<double2*>(p); p += 4 * (size_t)S.nvx;
+  m.ksc = p; p += (size_t)nfeat * (S.npts + 2);
   m.taps[0] = p; p += S.ntaps[0];
   m.taps[1] = p; p += S.ntaps[1];
+  m.phys = p; p += kNP_MAX + 2;
   m.cosa = p; p += S.n_angles;
   m.wsa = p; p += S.n_angles;
   m.red = p;
@@ -217,13 +225,45 @@ __device__ __forceinline__ void load_tables(const Smem& m, const KStatic& S, con
     m.W[i] = K.W[(size_t)slot * kNXi2 + i];
   }
   for (int i = tid; i < S.nvx; i += nthr) m.ht[i] = K.ht[(size_t)slot * S.nvx + i];
+  for (int i = tid; i < S.nvx - 1; i += nthr) {
+    double2 c01, c23;
+    hermite_coeffs(K.ht[(size_t)slot * S.nvx + i], K.ht[(size_t)slot * S.nvx + i + 1], S.dv, c01, c23);
+    m.hc[2 * i] = c01;
+    m.hc[2 * i + 1] = c23;
+  }
   if (with_taps) {
     for (int i = tid; i < S.ntaps[0]; i += nthr) m.taps[0][i] = S.taps[0][i];
     for (int i = tid; i < S.ntaps[1]; i += nthr) m.taps[1][i] = S.taps[1][i];
   }
   for (int i = tid; i < S.n_angles; i += nthr) { m.cosa[i] = S.cos_sa[i]; m.wsa[i] = S.w_sa[i]; }
-  T.zp = m.zp; T.W = m.W; T.ht = m.ht; T.nvx = S.nvx;
+  T.zp = m.zp; T.W = m.W; T.ht = m.ht; T.hc = m.hc; T.nvx = S.nvx;
   T.vx0 = S.vx0; T.dv = S.dv; T.idv = 1.0 / S.dv; T.vxlast = S.vx0 + (S.nvx - 1) * S.dv;
+}
+
+// physical parameters of lineout `xpar` -> LDS (one activation per thread, then Ti tying and fraction
+// renormalisation by one thread; ts_params.py:329-350, 543-563).  Contains workgroup barriers.
+template <int NI>
+__device__ __forceinline__ void stage_phys(const KStatic& S, const double* __restrict__ xpar, double* ph) {
+  constexpr int NPk = TSFF_NP(NI);
+  const int tid = threadIdx.x;
+  if (tid < NPk) {
+    const double v = xpar[tid];
+    ph[tid] = (S.p_sig[tid] ? sigmoid(v) : v) * S.p_scale[tid] + S.p_shift[tid];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double fsum = 0.0;
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+      const int o = TSFF_P_ION0 + 4 * s;
+      if (s > 0 && S.ti_same[s]) ph[o + TSFF_ION_TI] = ph[TSFF_P_ION0 + TSFF_ION_TI];
+      fsum += ph[o + TSFF_ION_FRACT];
+    }
+#pragma unroll
+    for (int s = 0; s < NI; ++s) ph[TSFF_P_ION0 + 4 * s + TSFF_ION_FRACT] /= fsum;
+    ph[NPk] = fsum;
+  }
+  __syncthreads();
 }
 
 // reductions over the 4 wavefronts of one feature half; every thread of the WORKGROUP must call them
@@ -286,6 +326,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   load_tables(m, S, K, S.shared_fe ? 0 : b, true, T);
 
   const double* __restrict__ xpar = K.params + (size_t)b * S.NP;
+  stage_phys<NI>(S, xpar, m.phys);
   const double lam_shift = S.lam_shift[f];
   const double* __restrict__ omgs = S.omgs[f];
   const int npts = S.npts, ppp = S.ppp, G = S.G, NA = S.n_angles;
@@ -293,31 +334,33 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   // (pointer arithmetic on the LDS base, not a runtime-indexed pointer array: keeps ds_* addressing)
   const int H = S.halo;
   double* __restrict__ xs = m.x[0] + half * (S.npts + 2 * H) + H;
-  double* __restrict__ ybs = m.yb[0] + half * (TSFF_NBINS + 2 * H) + H;
   for (int i = ht - H; i < npts + H; i += kHalf) xs[i] = 0.0;
-  for (int i = ht - H; i < TSFF_NBINS + H; i += kHalf) ybs[i] = 0.0;
   __syncthreads();
 
-  // ================= forward sweep over (lambda strip, gradient point, angle) =================
+  // ================= forward sweep over (gradient point, lambda strip, angle) =================
   // each thread owns strips of kStrip consecutive samples; the right neighbour's (xi_e, F) needed by the
   // finite difference along lambda (form_factor.py:258) is evaluated by the owner of the strip.
-  for (int c = 0; c < ppp; ++c) {
-    const int j0 = kStrip * (ht + kHalf * c);
-    // the frequency axis is read from global memory (L1/L2): the strip's first two samples once per
-    // chunk, the others one iteration ahead of their use so the load latency hides behind a whole point
-    const double ws_first = omgs[j0], ws_second = omgs[min(j0 + 1, npts - 1)];
-    for (int g = 0; g < G; ++g) {
-      LineS<NI> L;
-      {
-        Phys<NI> p;  // reloaded where needed instead of being kept live across the sweeps
-        load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
-        make_lines_uniform<NI>(p, lam_shift, g, G, L);
-      }
+  double* __restrict__ ksc = m.ksc + half * (S.npts + 2);  // k_s(lambda) of the current gradient point
+  for (int g = 0; g < G; ++g) {
+    LineS<NI> L;
+    {
+      Phys<NI> p;  // re-read from LDS where needed instead of being kept live across the sweeps
+      phys_from_lds<NI>(m.phys, p);
+      make_lines_uniform<NI>(p, lam_shift, g, G, L);
+    }
+    if (g > 0) __syncthreads();
+    for (int i = ht; i < npts; i += kHalf) ksc[i] = ks_eval(omgs[i], L.wpe2);  // angle independent (form_factor.py:218)
+    __syncthreads();
+    for (int c = 0; c < ppp; ++c) {
+      const int j0 = kStrip * (ht + kHalf * c);
+      // the frequency axis is read from global memory (L1/L2): the strip's first two samples once per
+      // chunk, the others one iteration ahead of their use so the load latency hides behind a whole point
+      const double ws_first = omgs[j0], ws_second = omgs[min(j0 + 1, npts - 1)];
       for (int a = 0; a < NA; ++a) {
         const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a] * invG);
         double ws = ws_first, wnext = ws_second;
         Base b0;
-        base_eval<NI>(ws, ks_eval(ws, L.wpe2), ct, L, T, b0);
+        base_eval<NI>(ws, ksc[j0], ct, L, T, b0);
         TSFF_UNROLL(TSFF_QUNROLL)
         for (int q = 0; q < kStrip; ++q) {
           const int j = j0 + q;
@@ -325,7 +368,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
           const double wsn = wnext;
           wnext = omgs[min(j + 2, npts - 1)];
           Base b1;
-          base_eval<NI>(wsn, ks_eval(wsn, L.wpe2), ct, L, T, b1);
+          base_eval<NI>(wsn, ksc[min(j + 1, npts - 1)], ct, L, T, b1);
           xs[j] += wa * point_forward<NI>(ws, b0, b1, has_next, L, T);
           b0 = b1;
           ws = wsn;
@@ -381,9 +424,8 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   const double amps = K.amps[f][b];
   double p_lam, p_amp1, p_amp2, p_amp3;
   {
-    Phys<NI> p;
-    load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
-    p_lam = uni(p.lam); p_amp1 = uni(p.amp1); p_amp2 = uni(p.amp2); p_amp3 = uni(p.amp3);
+    p_lam = uni(m.phys[TSFF_P_LAM]); p_amp1 = uni(m.phys[TSFF_P_AMP1]);
+    p_amp2 = uni(m.phys[TSFF_P_AMP2]); p_amp3 = uni(m.phys[TSFF_P_AMP3]);
   }
   const double* __restrict__ lamb = S.lam_bin[f];
   double Tb[4];  // dLoss/dT (MODE 1)
@@ -442,6 +484,8 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   sn = half_sum(sn, m.red, half, hw, lane);
   a1b = half_sum(a1b, m.red, half, hw, lane);
   a2b = half_sum(a2b, m.red, half, hw, lane);
+  // the spectrum buffer is dead (every bin has been formed, barriers above): reuse it for ybar [1024]
+  double* __restrict__ ybs = xs;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int pb = ht + kHalf * r;
@@ -462,6 +506,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       sx[2] += g * y0[2 * kHalf + t];
       sx[3] += g * y0[3 * kHalf + t];
     }
+    __syncthreads();  // every read of ybar is done before xbar overwrites the buffer
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = ht + kHalf * r;
@@ -470,13 +515,31 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       xs[i] = v * invG;
     }
   } else {
-    for (int i = ht; i < npts; i += kHalf) {
-      const int jlo = max(0, i + dmin), jhi = min(npts - 1, i + dmax);
-      double sv = 0.0;
-      for (int j = jlo; j <= jhi; ++j) sv += taps[j - i - dmin] * ybs[j / ppp];
-      if (f == TSFF_FEATURE_ELE && S.filt) sv *= S.filt[i];
-      xs[i] = sv * invG;
+    // generic points-per-pixel: xbar_i = sum_j ybar[j / ppp] g[j - i - dmin]; results are staged in registers
+    // chunk by chunk because ybar and xbar share the buffer
+    double keep[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < ppp; ++c) {
+      double sv4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ht + kHalf * (4 * c + r);
+        const int jlo = max(0, i + dmin), jhi = min(npts - 1, i + dmax);
+        double sv = 0.0;
+        for (int j = jlo; j <= jhi; ++j) sv += taps[j - i - dmin] * ybs[j / ppp];
+        if (f == TSFF_FEATURE_ELE && S.filt) sv *= S.filt[i];
+        sv4[r] = sv * invG;
+      }
+      if (c == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep[r] = sv4[r];  // indices < 1024 still hold ybar: written last
+      } else {  // ybar only lives in [0, 1024): samples beyond it can be written at once
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xs[ht + kHalf * (4 * c + r)] = sv4[r];
+      }
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[ht + kHalf * r] = keep[r];
   }
   __syncthreads();
 
@@ -490,10 +553,15 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     LineS<NI> L, LB;
     {
       Phys<NI> p;
-      load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+      phys_from_lds<NI>(m.phys, p);
       make_lines_uniform<NI>(p, lam_shift, g, G, L);
     }
     zero_lines<NI>(LB);
+    if (G > 1) {  // (with one gradient point the cache of the forward sweep is still valid)
+      __syncthreads();
+      for (int i = ht; i < npts; i += kHalf) ksc[i] = ks_eval(omgs[i], L.wpe2);
+      __syncthreads();
+    }
     for (int c = 0; c < ppp; ++c) {
       const int j0 = kStrip * (ht + kHalf * c);
       const double ws_first = omgs[j0], ws_second = omgs[min(j0 + 1, npts - 1)];
@@ -501,7 +569,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
         const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a]);
         double ws = ws_first, wnext = ws_second;
         Base b0;
-        base_eval<NI>(ws, ks_eval(ws, L.wpe2), ct, L, T, b0);
+        base_eval<NI>(ws, ksc[j0], ct, L, T, b0);
         double cxe = 0.0, cF = 0.0;
         TSFF_UNROLL(TSFF_QUNROLL)
         for (int q = 0; q < kStrip; ++q) {
@@ -510,7 +578,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
           const double wsn = wnext;
           wnext = omgs[min(j + 2, npts - 1)];
           Base b1;
-          base_eval<NI>(wsn, ks_eval(wsn, L.wpe2), ct, L, T, b1);
+          base_eval<NI>(wsn, ksc[min(j + 1, npts - 1)], ct, L, T, b1);
           BaseAdj ba;
           double xen, Fn;
           point_reverse<NI>(ws, b0, b1, has_next, L, T, xs[j] * wa, ba, xen, Fn, LB);
@@ -549,7 +617,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
 #pragma unroll
         for (int s = 0; s < NI; ++s) { LB.ixi[s] = lb[8 + 3 * s]; LB.a_i[s] = lb[9 + 3 * s]; LB.cs[s] = lb[10 + 3 * s]; }
         Phys<NI> p;
-        load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+        phys_from_lds<NI>(m.phys, p);
         double pbar[NPk];
 #pragma unroll
         for (int s = 0; s < NPk; ++s) pbar[s] = 0.0;
@@ -571,7 +639,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     if (nfeat > 1)
       for (int s = 0; s < NPk; ++s) gsum[s] += gsum[NPk + s];
     Phys<NI> p;
-    load_phys<NI>(xpar, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+    phys_from_lds<NI>(m.phys, p);
 #pragma unroll
     for (int s = 1; s < NI; ++s)
       if (S.ti_same[s]) {
