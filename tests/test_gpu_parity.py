@@ -151,10 +151,10 @@ def test_loss_value_matches_oracle(torch_mod):
     assert util.rel_err(I.cpu().numpy(), Io) < 1e-8
 
 
-def _grad_case(torch_mod, active, names, B, seed, n_ion=1, tweak=None, tol=1e-7):
+def _grad_case(torch_mod, active, names, B, seed, n_ion=1, tweak=None, tol=1e-7, ppp=1):
     from oracle import tsadar_oracle_torch as ot
 
-    cfg = decks.deck_fit(active=active, n_ion=n_ion)
+    cfg = decks.deck_fit(active=active, n_ion=n_ion, points_per_pixel=ppp)
     if tweak:
         tweak(cfg)
     sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B, seed=seed)
@@ -191,6 +191,13 @@ def test_gradient_matches_autodiff_all_leaves(torch_mod):
 def test_gradient_baseline_active_set(torch_mod):
     """a15 on the BASELINE active set {Te, ne, Ti, Va, lam, amp1}."""
     _grad_case(torch_mod, ("Te", "ne", "Ti", "Va", "lam", "amp1"), ["Te", "ne", "Ti_1", "Va", "lam", "amp1"], B=3, seed=9)
+
+
+def test_gradient_two_points_per_pixel(torch_mod):
+    """a12/a15 with points_per_pixel = 2 (2048 wavelength samples binned to 1024): the generic
+    convolution / binning adjoint."""
+    _grad_case(torch_mod, ("Te", "ne", "Ti", "Va", "lam", "amp1", "amp2", "amp3"),
+               ["Te", "ne", "Ti_1", "Va", "lam", "amp1", "amp2", "amp3"], B=2, seed=11, ppp=2)
 
 
 def test_gradient_two_ions_three_gradient_points(torch_mod):
