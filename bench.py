@@ -45,11 +45,26 @@ def _cpu_worker_init():
     from oracle import tsadar_oracle_torch  # noqa: F401  (import cost outside the timed region)
 
 
+def _cpu_prepare(args):
+    """(untimed) synthetic 'measured' data of one lineout: oracle forward at the truth parameters + 1 % noise."""
+    cfg, sa1, truth, seed = args
+    from oracle import tsadar_oracle as orc
+
+    unit = dict(e_amps=np.ones(1), i_amps=np.ones(1), noise_e=np.zeros((1, 1024)), noise_i=np.zeros((1, 1024)))
+    E, I, lE, lI = orc.ts_diag(cfg, sa1, truth, unit)
+    nrng = np.random.default_rng(seed)
+    E = E * (1 + 0.01 * nrng.standard_normal(E.shape))
+    I = I * (1 + 0.01 * nrng.standard_normal(I.shape))
+    iaw, blue, red = orc.fit_masks(cfg, lE, lI)
+    return dict(e_data=E, i_data=I, e_amps=np.array([E[0][blue[0] | red[0]].max()]), i_amps=np.array([I[0][iaw[0]].max()]),
+                noise_e=np.zeros((1, 1024)), noise_i=np.zeros((1, 1024)))
+
+
 def _cpu_worker(args):
-    cfg, sa, normed, batch, i_norm, e_norm, names = args
+    cfg, sa, normed, batch, names = args
     from oracle import tsadar_oracle_torch as ot
 
-    val, g, _, _ = ot.value_and_grad(cfg, sa, normed, batch, i_norm, e_norm, names)
+    val, g, _, _ = ot.value_and_grad(cfg, sa, normed, batch, float(batch["i_data"].max()), float(batch["e_data"].max()), names)
     return val
 
 
@@ -61,12 +76,11 @@ def cpu_baseline(cfg, B, n_sample):
     import multiprocessing as mp
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import tsadar_oracle as orc
     from tsadar_amd import _lib as L
     from tsadar_amd import synthetic as S
     from tsadar_amd.calibration import sa_lookup
 
-    n = n_sample
+    n = min(n_sample, B)
     rng = np.random.default_rng(S.SEED)
     truth = S.draw_params(cfg, B, rng)
     rng.integers(1 << 31)  # the draw make_batch() consumes on the GPU leg
@@ -84,30 +98,21 @@ def cpu_baseline(cfg, B, n_sample):
             "Te_gradient": X[b:b + 1, L.P_TE_GRADIENT], "ud": X[b:b + 1, L.P_UD], "Va": X[b:b + 1, L.P_VA],
         }
 
-    unit = dict(e_amps=np.ones(1), i_amps=np.ones(1), noise_e=np.zeros((1, 1024)), noise_i=np.zeros((1, 1024)))
-    nrng = np.random.default_rng(S.SEED + 1)
     names = ["Te", "ne", "Ti_1", "Va", "lam", "amp1"]
-    tasks = []
-    for b in range(n):
-        E, I, lE, lI = orc.ts_diag(cfg, sa1, named(truth.X, b), unit)
-        E = E * (1 + 0.01 * nrng.standard_normal(E.shape))
-        I = I * (1 + 0.01 * nrng.standard_normal(I.shape))
-        iaw, blue, red = orc.fit_masks(cfg, lE, lI)
-        bt = dict(e_data=E, i_data=I, e_amps=np.array([E[0][blue[0] | red[0]].max()]), i_amps=np.array([I[0][iaw[0]].max()]),
-                  noise_e=np.zeros((1, 1024)), noise_i=np.zeros((1, 1024)))
-        tasks.append((cfg, sa1, named(guess.X, b), bt, float(I.max()), float(E.max()), names))
     cores = max(1, min(os.cpu_count() or 1, 16, n))
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores, initializer=_cpu_worker_init) as pool:
+        batches = pool.map(_cpu_prepare, [(cfg, sa1, named(truth.X, b), S.SEED + 1 + b) for b in range(n)], chunksize=4)
+        tasks = [(cfg, sa1, named(guess.X, b), batches[b], names) for b in range(n)]
         pool.map(_cpu_worker, tasks[:cores])  # warm-up: imports, W-table cache, allocator
         t0 = time.perf_counter()
-        pool.map(_cpu_worker, tasks, chunksize=1)
+        pool.map(_cpu_worker, tasks, chunksize=4)
         dt = time.perf_counter() - t0
     return {
         "value": n / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
         "sample": (f"first {n} of the {B} lineouts (same seeded parameter draws), loss+grad of one EPW+IAW spectrum each by "
                    f"torch-f64 reverse-mode autodiff of the oracle (CPU restatement of the reference algorithm, W table cached), "
-                   f"{cores} processes x 1 thread, {dt:.1f} s wall"),
+                   f"{cores} processes x 1 thread, {dt:.1f} s wall = {dt * cores:.0f} core-seconds"),
     }
 
 
@@ -118,7 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="lineouts per GPU")
     ap.add_argument("--ppp", type=int, default=1, help="points per pixel (1 -> 1024 wavelength points per feature)")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="lineouts of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="lineouts of the CPU baseline (0 = skip)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: forward-only (not the headline metric)")
     args = ap.parse_args()
 
@@ -215,6 +220,14 @@ def main():
         return
 
     kavg_s = float(np.mean(ktimes)) * 1e-3 if ktimes.size else float("nan")
+    # HBM bytes per launch from the PMC passes of this round (rocprofv3 --pmc cannot run inside bench.py):
+    # profiles/r01_traffic.json, produced by scripts/profile_round.sh on the same workload
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tfile) and not args.forward_only:
+        tj = json.load(open(tfile))
+        if tj.get("B") == B and tj.get("ppp") == args.ppp:
+            traffic = tj["hbm_bytes_per_launch"]
     abytes = algorithmic_bytes(eng.NP, with_noise=False) if not args.forward_only else (eng.NP * 8 + 16 + 2 * 1024 * 8)
     achieved = B * abytes / kavg_s / 1e9
     res = {
@@ -248,7 +261,9 @@ def main():
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": achieved * 1e9 / HBM_PEAK,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
+            "algorithmic_bytes_per_launch": B * abytes,
             "kernel": "k_spectrum<1,1>" if not args.forward_only else "k_spectrum<1,0>",
             "kernel_avg_ms": kavg_s * 1e3,
             "algorithmic_bytes_per_spectrum": abytes,
