@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TSFF_ABI_VERSION 1
+#define TSFF_ABI_VERSION 2
 
 /* ---- parameter slots of one lineout: params[b][TSFF_NP(n_ion)] (normalised leaves of the
  * reference's ThomsonParams pytree, core/modules/ts_params.py:49-60,395-420,253-262) ---------- */
@@ -102,6 +102,10 @@ typedef struct tsff_config {
   const double *xi2;       /* [TSFF_NXI2] */
   const double *zprime_re; /* [TSFF_NXI2] rdWT.txt interpolated on xi2 */
   const double *zprime_im; /* [TSFF_NXI2] */
+  /* log-ratio table of ratintn.py:49 on the (xi1, xi2) grids, Lg[q][i] = log|(gav + gdif/2)/(gav - gdif/2)|,
+   * [TSFF_NXI2][TSFF_NXI1] with the two unused columns (i >= 1022) zero.  Required unless fe_mode == SHARED:
+   * per-lineout W tables are then two matrix-vector products with this constant table. */
+  const double *lg_table;
 
   /* instrument response (irf.py:50-132): Gaussian taps g[d], y[j] = sum_d g[d] x[j-d],
    * d = tap_dmin .. tap_dmin + n_taps - 1 (the reference's "same" alignment) */
@@ -167,7 +171,8 @@ int tsff_forward(tsff_handle *h, const double *params, const double *fe, const d
  *   loss_terms[3] (device): un-weighted masked sums  S_iaw, S_blue, S_red  over these B lineouts;
  *   total loss = sum_k weights[k] * S_k (summed over ranks).
  *   grad (device) [B][NP]: d(total loss)/d(params[b][slot]) for slots with grad_mask[slot] != 0
- *   (HOST uint8 [NP]), 0 elsewhere.  ThryE/ThryI may be NULL. */
+ *   (HOST uint8 [NP]), 0 elsewhere.  The DLM order slot (TSFF_P_M) is differentiable when
+ *   fe_mode == TSFF_FE_DLM (through the ln f_e and W tables).  ThryE/ThryI may be NULL. */
 int tsff_loss_grad(tsff_handle *h, const double *params, const double *fe, const double *e_data,
                    const double *i_data, const double *e_amps, const double *i_amps,
                    const double *noise_e, const double *noise_i, int32_t B,

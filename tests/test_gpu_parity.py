@@ -193,6 +193,53 @@ def test_gradient_baseline_active_set(torch_mod):
     _grad_case(torch_mod, ("Te", "ne", "Ti", "Va", "lam", "amp1"), ["Te", "ne", "Ti_1", "Va", "lam", "amp1"], B=3, seed=9)
 
 
+def test_gradient_dlm_order(torch_mod):
+    """the reference's canonical active set {Te, ne, m, amp1, amp2, lam} -- the gradient
+    w.r.t. the super-Gaussian order m flows through the ln f_e Hermite table and the W table
+    (per-lineout tables by k_fe_vectors + k_wgemm)."""
+    def tweak(cfg):
+        cfg["parameters"]["electron"]["fe"]["params"]["m"]["val"] = 2.7
+
+    B = 3
+    names = ["Te", "ne", "m", "amp1", "amp2", "lam"]
+    from oracle import tsadar_oracle_torch as ot
+
+    cfg = decks.deck_fit(active=("Te", "ne", "m", "amp1", "amp2", "lam"))
+    tweak(cfg)
+    sa = util.sa_fit(B)
+    batch = util.synthetic_batch(cfg, sa, B, seed=41)
+    normed = util.random_lineouts(cfg, B, seed=43, ranges=dict(m=(2.05, 4.4)))
+    i_norm, e_norm = orc.loss_norms(cfg, batch)
+    eng = _engine(cfg, sa)
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    terms, grad, E, I = eng.loss_grad(util.normed_to_matrix(normed, 1), batch, w, eng.slots.active.astype(np.uint8), want_spectra=True)
+    val, ref, Eo, Io = ot.value_and_grad(cfg, sa, normed, batch, i_norm, e_norm, names)
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-8 and util.rel_err(I.cpu().numpy(), Io) < 1e-8
+    assert abs(float(np.dot(terms.cpu().numpy(), w)) - val) < 1e-9 * abs(val)
+    G = util.matrix_to_named(grad.cpu().numpy(), names)
+    scale = max(np.max(np.abs(v)) for v in ref.values())
+    for k in names:
+        assert np.max(np.abs(G[k] - ref[k])) / scale < 1e-7, (k, G[k], ref[k])
+
+
+def test_per_lineout_tables_match_log_sum(torch_mod):
+    """The matrix-vector form of the W table (k_fe_vectors + k_wgemm, per-lineout f_e) equals the direct
+    1640 x 1022 logarithm sum (k_fe_prepare) and the oracle: forward with explicit per-lineout f_e."""
+    from tsadar_amd import _lib
+
+    cfg = decks.deck_fit()
+    B = 5
+    sa = util.sa_fit(B)
+    eng = _engine(cfg, sa, fe_mode=_lib.FE_PER_LINEOUT)
+    nvx = cfg["parameters"]["electron"]["fe"]["nvx"]
+    fes = np.stack([orc.dlm_fe(m, nvx) for m in (2.0, 2.3, 3.1, 4.2, 5.0)])
+    normed = util.random_lineouts(cfg, B, seed=47)
+    batch = dict(e_amps=np.ones(B), i_amps=np.ones(B), noise_e=np.zeros((B, 1024)), noise_i=np.zeros((B, 1024)))
+    Eo, Io, _, _ = orc.ts_diag(cfg, sa, normed, batch, fe_batch=fes)
+    E, I = eng.forward(util.normed_to_matrix(normed, 1), batch["e_amps"], batch["i_amps"], fe=fes)
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-8 and util.rel_err(I.cpu().numpy(), Io) < 1e-8
+
+
 def test_gradient_two_points_per_pixel(torch_mod):
     """a12/a15 with points_per_pixel = 2 (2048 wavelength samples binned to 1024): the generic
     convolution / binning adjoint."""
@@ -362,11 +409,13 @@ def test_errors_are_reported_not_swallowed(torch_mod):
     from tsadar_amd import _lib
     from tsadar_amd.engine import Engine
 
-    cfg = decks.deck_fit(active=("Te", "ne", "m"))
+    cfg = decks.deck_fit()
     sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, 1, seed=37)
-    eng = Engine(cfg, sa)
+    eng = Engine(cfg, sa)  # shared Maxwellian: the DLM order is not a leaf of this engine
+    gm = eng.slots.active.astype(np.uint8)
+    gm[_lib.P_M] = 1
     with pytest.raises(_lib.TsffError, match="DLM order m"):
-        eng.loss_grad(util.normed_to_matrix(normed, 1), batch, eng.loss_weights(1, i_norm, e_norm), eng.slots.active.astype(np.uint8))
+        eng.loss_grad(util.normed_to_matrix(normed, 1), batch, eng.loss_weights(1, i_norm, e_norm), gm)
     cfg = decks.deck_fit()
     cfg["other"]["PhysParams"]["norm"] = 1
     with pytest.raises(_lib.TsffError, match="norm"):

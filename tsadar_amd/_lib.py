@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsff.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_ION = 4
 NBINS = 1024
 NXI1 = 1024
@@ -56,6 +56,7 @@ class TsffConfig(C.Structure):
         ("xi2", c_double_p),
         ("zprime_re", c_double_p),
         ("zprime_im", c_double_p),
+        ("lg_table", c_double_p),
         ("n_taps_ele", C.c_int32),
         ("tap_dmin_ele", C.c_int32),
         ("taps_ele", c_double_p),

@@ -117,6 +117,8 @@ struct Tables {
   const double* W;     // [1640] Re(chi_e) table on xi2
   const double2* ht;   // [nvx]  (ln fe, node slope) on vx            (k_fe_prepare)
   const double2* hc;   // [2*(nvx-1)] cubic coefficients per interval: (f0, m0), (c2, c3)   (spectrum kernels)
+  const double2* hcm;  // the same for d(ln fe)/dm (gradient w.r.t. the DLM order), or nullptr
+  const double* Wm;    // [1640] dW/dm, or nullptr
   double vx0, dv, idv, vxlast;
   int nvx;
 };
@@ -206,6 +208,7 @@ template <int NI>
 struct LineS {
   double wpe2, wL, kL, ivTe, a_e, pref, Ud, Vd;
   double i2wL;  // 2 / wL (derived; carries no adjoint of its own)
+  double m;     // adjoint accumulator of the DLM order (through the ln f_e and W tables); unused in the forward
   double ixi[NI], a_i[NI], cs[NI];
 };
 
@@ -221,6 +224,7 @@ __device__ __forceinline__ void make_lines(const Phys<NI>& p, double lam_shift, 
   const double Te_g = p.Te * (1.0 + p.teg * cg);
   L.wL = kOmgLnum / (p.lam + lam_shift);
   L.i2wL = 2.0 / L.wL;
+  L.m = 0.0;
   L.wpe2 = kC0sq * ne_g;
   L.kL = sqrt(L.wL * L.wL - L.wpe2) / kC;
   L.ivTe = 1.0 / sqrt(Te_g / kMe);
@@ -312,6 +316,7 @@ __device__ __forceinline__ void make_lines_adjoint(const Phys<NI>& p, double lam
   pb[TSFF_P_TE_GRADIENT] += Te_gb * p.Te * cg;
   pb[TSFF_P_UD] += LB.Ud * 1e6;
   pb[TSFF_P_VA] += LB.Vd * 1e6;
+  pb[TSFF_P_M] += LB.m;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -447,7 +452,7 @@ struct BaseAdj {  // adjoints flowing into base quantities of a point
 
 // reverse of point_forward: given Pbar, produce adjoints of this point's base quantities (ba),
 // of the right neighbour's (xe, F) (xen, Fn), and accumulate lineout-scalar adjoints into LB.
-template <int NI>
+template <int NI, bool WM = false>
 __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Base& bn, bool has_next,
                                               const LineS<NI>& L, const Tables& T, double Pbar,
                                               BaseAdj& ba, double& xen, double& Fn, LineS<NI>& LB) {
@@ -496,7 +501,13 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
   const double cerb = erb + ce2b * 2.0 * cer, ceib = eib + ce2b * 2.0 * cei;
   const double creb = erb + ci2b * 2.0 * (1.0 + cre), cimb = eib + ci2b * 2.0 * cim;
   double ike2b = -cerb * Wl + ceib * kPi * D;
-  ba.xe = -cerb * ike2 * dW;
+  const double Wlb = -cerb * ike2;  // adjoint of the interpolated W
+  ba.xe = Wlb * dW;
+  if (WM) {  // W depends on the DLM order through the table itself
+    double Wml, dWm;
+    w_lookup(T.Wm, b.xe, Wml, dWm);
+    LB.m += Wlb * Wml;
+  }
   const double Db = ceib * kPi * ike2;
   // D = (Fn - F) * idx
   Fn = Db * idx;
@@ -524,10 +535,18 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
 }
 
 // reverse of base_eval
-template <int NI>
-__device__ __forceinline__ void base_reverse(double ct, const Base& b, const LineS<NI>& L, const BaseAdj& ba,
-                                             LineS<NI>& LB) {
-  const double xeb = ba.xe + ba.F * b.F * b.dH;
+template <int NI, bool WM = false>
+__device__ __forceinline__ void base_reverse(double ct, const Base& b, const LineS<NI>& L, const Tables& T,
+                                             const BaseAdj& ba, LineS<NI>& LB) {
+  const double Hb = ba.F * b.F;  // adjoint of H = ln f_e(xi_e)
+  if (WM) {  // d ln f_e(xi_e)/dm: Hermite interpolant of the tangent table (zero outside the vx grid)
+    Tables Tm = T;
+    Tm.hc = T.hcm;
+    double Hm, dHm;
+    hermite_lookup_c(Tm, b.xe, Hm, dHm);
+    LB.m += (b.xe < T.vx0 || b.xe > T.vxlast) ? 0.0 : Hb * Hm;
+  }
+  const double xeb = ba.xe + Hb * b.dH;
   const double vph = b.wd * b.ik, k = b.k2 * b.ik;
   // xe = (vph - Ud) * ivTe
   const double vphb = xeb * L.ivTe;
@@ -564,7 +583,7 @@ __device__ __forceinline__ void phys_from_lds(const double* ph, Phys<NI>& p) {
 
 template <int NI>
 __device__ __forceinline__ void zero_lines(LineS<NI>& L) {
-  L.wpe2 = L.wL = L.kL = L.ivTe = L.a_e = L.pref = L.Ud = L.Vd = L.i2wL = 0.0;
+  L.wpe2 = L.wL = L.kL = L.ivTe = L.a_e = L.pref = L.Ud = L.Vd = L.i2wL = L.m = 0.0;
 #pragma unroll
   for (int s = 0; s < NI; ++s) L.ixi[s] = L.a_i[s] = L.cs[s] = 0.0;
 }

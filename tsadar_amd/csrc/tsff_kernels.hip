@@ -36,6 +36,7 @@ struct KStatic {
   const double* p_shift;
   const uint8_t* p_sig;
   const double* dlm_table;   // [nvx][31]
+  const double* lg;          // [1640][1024] log-ratio table of the rationally-centred integration (ratintn.py:49), zero padded
   uint8_t ti_same[TSFF_MAX_ION];
   double vx0, dv;
 };
@@ -45,6 +46,8 @@ struct KCall {
   const double* params;  // [B][NP]
   const double2* ht;     // [slots][nvx]
   const double* W;       // [slots][1640]
+  const double2* htm;    // [slots][nvx]  d(ln fe, slope)/dm   (WITH_M)
+  const double* Wm;      // [slots][1640] dW/dm                (WITH_M)
   const double* amps[2];
   const double* noise[2];
   const double* data[2];
@@ -160,6 +163,186 @@ __global__ __launch_bounds__(kThreads) void k_fe_prepare(KStatic S, const double
 }
 
 // ------------------------------------------------------------------------------------------
+// Per-lineout distribution functions (fe_mode DLM / PER_LINEOUT).  The Re(chi_e) table is linear in
+// ratdf: with h_i = xi1[i+1]-xi1[i], s_i = fdif_i/h_i, A_i = fav_i - xi1mid_i s_i,
+//   W[q] = sum_i fdif_i + sum_i Lg[q][i] (A_i + xi2[q] s_i),   Lg[q][i] = log|(gav+gdif/2)/(gav-gdif/2)|
+// (ratintn.py:41-52 with gdif = zdif; the small-gdif branch never triggers on this grid).  Lg is a
+// constant 1640x1022 table, so the 1.68 M logarithms per f_e of k_fe_prepare become two matrix-vector
+// products per lineout, done for the whole batch by k_wgemm.  The derivative with respect to the DLM
+// order m rides along as a second pair of vectors (tangent of f_e -> ln f_e -> ratmod -> ratdf).
+//
+// k_fe_vectors: grid B, 256 threads.  Outputs ht/htm [B][nvx], X [B][4][1024] = (A, s, dA/dm, ds/dm) zero
+// padded, cst [B][2] = (sum fdif, d/dm).
+// ------------------------------------------------------------------------------------------
+template <int NI>
+__global__ __launch_bounds__(kThreads) void k_fe_vectors(KStatic S, const double* __restrict__ fe_in, int fe_mode,
+                                                         const double* __restrict__ params, double2* __restrict__ ht_out,
+                                                         double2* __restrict__ htm_out, double* __restrict__ X,
+                                                         double* __restrict__ cst) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* ht = reinterpret_cast<double2*>(smem);         // [nvx]
+  double2* htm = ht + S.nvx;                              // [nvx]
+  double2* hc = htm + S.nvx;                              // [2 nvx]
+  double2* hcm = hc + 2 * S.nvx;                          // [2 nvx]
+  double* lnfe = reinterpret_cast<double*>(hcm + 2 * S.nvx);  // [nvx]
+  double* dln = lnfe + S.nvx;                             // [nvx]
+  double* rat = dln + S.nvx;                              // [1024] ratmod -> ratdf
+  double* ratm = rat + kNXi1;                             // [1024]
+  double* rdf = ratm + kNXi1;                             // [1024]
+  double* rdfm = rdf + kNXi1;                             // [1024]
+  double* red = rdfm + kNXi1;                             // [8]
+  const int b = blockIdx.x, tid = threadIdx.x, nvx = S.nvx;
+
+  if (fe_mode == TSFF_FE_DLM) {
+    Phys<NI> p;
+    load_phys<NI>(params + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, true, p);
+    const double m = p.m;
+    double u = (m - 2.0) * 10.0;
+    int k = (int)u;
+    k = k < 0 ? 0 : (k > TSFF_DLM_NM - 2 ? TSFF_DLM_NM - 2 : k);
+    double t = (m - (2.0 + 0.1 * k)) * 10.0;
+    const bool inside = m >= 2.0 && m <= 5.0;   // jnp.interp clamps outside the m axis: zero slope there
+    t = m < 2.0 ? 0.0 : (m > 5.0 ? 1.0 : t);
+    double part = 0.0, dpart = 0.0;
+    for (int i = tid; i < nvx; i += kThreads) {
+      const double a = S.dlm_table[i * TSFF_DLM_NM + k], c = S.dlm_table[i * TSFF_DLM_NM + k + 1];
+      const double f = a + t * (c - a);
+      const double df = inside ? (c - a) * 10.0 : 0.0;
+      lnfe[i] = f;
+      dln[i] = df;
+      part += f;
+      dpart += df;
+    }
+    const double tot = block_sum(part, red);
+    const double dtot = block_sum(dpart, red);
+    for (int i = tid; i < nvx; i += kThreads) {
+      const double f = lnfe[i];
+      dln[i] = dln[i] / f - dtot / tot;               // d ln fe / dm
+      lnfe[i] = log(f / tot / S.dv);                  // base.py:293
+    }
+  } else {
+    for (int i = tid; i < nvx; i += kThreads) { lnfe[i] = log(fe_in[(size_t)b * nvx + i]); dln[i] = 0.0; }
+  }
+  __syncthreads();
+  for (int i = tid; i < nvx; i += kThreads) {
+    const double dl = i > 0 ? (lnfe[i] - lnfe[i - 1]) / S.dv : 0.0, dr = i < nvx - 1 ? (lnfe[i + 1] - lnfe[i]) / S.dv : 0.0;
+    const double ml = i > 0 ? (dln[i] - dln[i - 1]) / S.dv : 0.0, mr = i < nvx - 1 ? (dln[i + 1] - dln[i]) / S.dv : 0.0;
+    const double sl = i == 0 ? dr : (i == nvx - 1 ? dl : 0.5 * (dl + dr));
+    const double sm = i == 0 ? mr : (i == nvx - 1 ? ml : 0.5 * (ml + mr));
+    ht[i] = make_double2(lnfe[i], sl);
+    htm[i] = make_double2(dln[i], sm);
+    ht_out[(size_t)b * nvx + i] = ht[i];
+    htm_out[(size_t)b * nvx + i] = htm[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < nvx - 1; i += kThreads) {
+    hermite_coeffs(ht[i], ht[i + 1], S.dv, hc[2 * i], hc[2 * i + 1]);
+    hermite_coeffs(htm[i], htm[i + 1], S.dv, hcm[2 * i], hcm[2 * i + 1]);
+  }
+  __syncthreads();
+  Tables T;
+  T.zp = nullptr; T.W = nullptr; T.ht = ht; T.hc = hc; T.nvx = nvx;
+  T.vx0 = S.vx0; T.dv = S.dv; T.idv = 1.0 / S.dv; T.vxlast = S.vx0 + (nvx - 1) * S.dv;
+  Tables Tm = T;
+  Tm.hc = hcm;
+  for (int i = tid; i < kNXi1; i += kThreads) {
+    const double x = S.xi1[i];
+    double H, dH, Hm, dHm;
+    hermite_lookup_c(T, x, H, dH);
+    hermite_lookup_c(Tm, x, Hm, dHm);
+    const bool out = x < T.vx0 || x > T.vxlast;
+    const double r = exp(H);
+    rat[i] = r;
+    ratm[i] = out ? 0.0 : r * Hm;
+  }
+  __syncthreads();
+  const double h1 = S.xi1[1] - S.xi1[0];
+  for (int i = tid; i < kNXi1; i += kThreads) {
+    double g, gm;
+    if (i == 0) { g = (rat[1] - rat[0]) / h1; gm = (ratm[1] - ratm[0]) / h1; }
+    else if (i == kNXi1 - 1) { g = (rat[i] - rat[i - 1]) / h1; gm = (ratm[i] - ratm[i - 1]) / h1; }
+    else { g = (rat[i + 1] - rat[i - 1]) / (2.0 * h1); gm = (ratm[i + 1] - ratm[i - 1]) / (2.0 * h1); }
+    rdf[i] = g;
+    rdfm[i] = gm;
+  }
+  __syncthreads();
+  double c0 = 0.0, c1 = 0.0;
+  double* Xb = X + (size_t)b * 4 * kNXi1;
+  for (int i = tid; i < kNXi1; i += kThreads) {
+    double A = 0.0, Bs = 0.0, Am = 0.0, Bm = 0.0;
+    if (i < kNXi1 - 2) {
+      const double x0 = S.xi1[i], x1 = S.xi1[i + 1];
+      const double ih = 1.0 / (x1 - x0), mid = 0.5 * (x1 + x0);
+      const double fd = rdf[i + 1] - rdf[i], fa = 0.5 * (rdf[i + 1] + rdf[i]);
+      const double fdm = rdfm[i + 1] - rdfm[i], fam = 0.5 * (rdfm[i + 1] + rdfm[i]);
+      Bs = fd * ih; A = fa - mid * Bs;
+      Bm = fdm * ih; Am = fam - mid * Bm;
+      c0 += fd; c1 += fdm;
+    }
+    Xb[i] = A; Xb[kNXi1 + i] = Bs; Xb[2 * kNXi1 + i] = Am; Xb[3 * kNXi1 + i] = Bm;
+  }
+  c0 = block_sum(c0, red);
+  c1 = block_sum(c1, red);
+  if (tid == 0) { cst[2 * b] = c0; cst[2 * b + 1] = c1; }
+}
+
+// k_wgemm: W[b][q] = c0_b + sum_i Lg[q][i] (A_b[i] + xi2[q] s_b[i]) and the same for d/dm.
+// 64 (q) x 64 (vectors = 16 lineouts x 4) tile per 256-thread workgroup, 4 x 4 register tile per thread,
+// K = 1024 in steps of 16 through LDS.  FP64 VALU FMAs (no MFMA: same peak on this chip, and the rest of the
+// path is VALU anyway).
+constexpr int kGM = 64, kGN = 64, kGK = 16;
+__global__ __launch_bounds__(kThreads) void k_wgemm(const double* __restrict__ Lg, const double* __restrict__ X,
+                                                    const double* __restrict__ cst, const double* __restrict__ xi2,
+                                                    int B, double* __restrict__ W, double* __restrict__ Wm) {
+  __shared__ double As[kGK][kGM + 2];
+  __shared__ double Bs[kGK][kGN + 2];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int q0 = blockIdx.x * kGM, b0 = blockIdx.y * (kGN / 4);
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  const int lr = tid >> 2, lk = (tid & 3) * 4;  // this thread stages row lr, columns lk..lk+3 of both tiles
+  const int qa = q0 + lr;
+  const int bv = b0 + (lr >> 2), cv = lr & 3;
+  const double* __restrict__ arow = Lg + (size_t)min(qa, kNXi2 - 1) * kNXi1 + lk;
+  const double* __restrict__ brow = X + ((size_t)min(bv, B - 1) * 4 + cv) * kNXi1 + lk;
+  const bool aok = qa < kNXi2, bok = bv < B;
+  for (int k0 = 0; k0 < kNXi1; k0 += kGK) {
+    const double2 a0 = *reinterpret_cast<const double2*>(arow + k0), a1 = *reinterpret_cast<const double2*>(arow + k0 + 2);
+    const double2 c0 = *reinterpret_cast<const double2*>(brow + k0), c1 = *reinterpret_cast<const double2*>(brow + k0 + 2);
+    __syncthreads();
+    As[lk][lr] = aok ? a0.x : 0.0; As[lk + 1][lr] = aok ? a0.y : 0.0; As[lk + 2][lr] = aok ? a1.x : 0.0; As[lk + 3][lr] = aok ? a1.y : 0.0;
+    Bs[lk][lr] = bok ? c0.x : 0.0; Bs[lk + 1][lr] = bok ? c0.y : 0.0; Bs[lk + 2][lr] = bok ? c1.x : 0.0; Bs[lk + 3][lr] = bok ? c1.y : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kGK; ++k) {
+      double a[4], c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; c[i] = Bs[k][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(a[i], c[j], acc[i][j]);
+    }
+  }
+  const int bb = b0 + tx;
+  if (bb < B) {
+    const double c0 = cst[2 * bb], c1 = cst[2 * bb + 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = q0 + ty * 4 + i;
+      if (q < kNXi2) {
+        const double x2 = xi2[q];
+        W[(size_t)bb * kNXi2 + q] = c0 + acc[i][0] + x2 * acc[i][1];
+        Wm[(size_t)bb * kNXi2 + q] = c1 + acc[i][2] + x2 * acc[i][3];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // shared helpers of the spectrum kernels
 // ------------------------------------------------------------------------------------------
 constexpr int kHalf = 256;  // threads per feature inside a k_spectrum workgroup (4 wavefronts)
@@ -180,6 +363,8 @@ struct Smem {
   double* yb[2];  // [1024]   adjoint of the binned spectrum (MODE 1)
   double* taps[2];
   double2* hc;    // [2*(nvx-1)] Hermite coefficients per interval
+  double2* hcm;   // the same for d ln fe / dm
+  double* Wm;     // [1640] dW/dm
   double* ksc;    // [nfeat][npts + 1] k_s cache of the current gradient point
   double* phys;   // [kNP_MAX + 1] physical parameters of this lineout
   double* cosa;   // [n_angles]
@@ -187,27 +372,34 @@ struct Smem {
   double* red;    // [8 * kNP_MAX + 64]
 };
 
-// LDS budget (in doubles) of one k_spectrum / k_form_factor workgroup
-__host__ __device__ inline size_t smem_doubles(const KStatic& S, int nfeat) {
-  return 2 * (size_t)(kNXi2 + S.nvx) + kNXi2 + (size_t)nfeat * ((size_t)S.npts + 2 * (size_t)S.halo) + 4 * (size_t)S.nvx +
-         (size_t)nfeat * ((size_t)S.npts + 2) + S.ntaps[0] + S.ntaps[1] + 2 * (size_t)S.n_angles + 11 * kNP_MAX + 66;
+// LDS budget (in doubles) of one k_spectrum / k_form_factor workgroup holding `nfeat` features;
+// with_m: tangent tables of the DLM order; with_ks: k_s cache
+__host__ __device__ inline size_t smem_doubles(const KStatic& S, int nfeat, bool with_m, bool with_ks) {
+  size_t n = 2 * (size_t)(kNXi2 + S.nvx) + kNXi2 + 4 * (size_t)S.nvx;                    // zp, ht, W, hc
+  if (with_m) n += 4 * (size_t)S.nvx + kNXi2;                                               // hcm, Wm
+  n += (size_t)nfeat * ((size_t)S.npts + 2 * (size_t)S.halo);                               // spectrum buffers
+  if (with_ks) n += (size_t)nfeat * ((size_t)S.npts + 2);                                   // k_s cache
+  n += S.ntaps[0] + S.ntaps[1] + 2 * (size_t)S.n_angles + 11 * kNP_MAX + 66;                // taps, angles, phys, scratch
+  return n;
 }
 
-__device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int nfeat) {
+__device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int nfeat, bool with_m, bool with_ks) {
   Smem m;
   m.zp = reinterpret_cast<double2*>(smem);
   m.ht = m.zp + kNXi2;
   m.W = reinterpret_cast<double*>(m.ht + S.nvx);
   double* p = m.W + kNXi2;
-  // x / yb buffers carry `halo` zeros on both sides so the convolutions need no bounds checks
-  // (one buffer per feature holds, in turn, the model spectrum x, the adjoint of the binned spectrum and
-  //  the adjoint of x)
+  // one buffer per feature holds, in turn, the model spectrum x, the adjoint of the binned spectrum and the
+  // adjoint of x; `halo` zeros on both sides so the convolutions need no bounds checks
   m.x[0] = p; p += (size_t)nfeat * (S.npts + 2 * S.halo);
   m.x[1] = nullptr;
   m.yb[0] = nullptr;
   m.yb[1] = nullptr;
   m.hc = reinterpret_cast<double2*>(p); p += 4 * (size_t)S.nvx;
-  m.ksc = p; p += (size_t)nfeat * (S.npts + 2);
+  m.hcm = nullptr; m.Wm = nullptr;
+  if (with_m) { m.hcm = reinterpret_cast<double2*>(p); p += 4 * (size_t)S.nvx; m.Wm = p; p += kNXi2; }
+  m.ksc = nullptr;
+  if (with_ks) { m.ksc = p; p += (size_t)nfeat * (S.npts + 2); }
   m.taps[0] = p; p += S.ntaps[0];
   m.taps[1] = p; p += S.ntaps[1];
   m.phys = p; p += kNP_MAX + 2;
@@ -231,12 +423,21 @@ __device__ __forceinline__ void load_tables(const Smem& m, const KStatic& S, con
     m.hc[2 * i] = c01;
     m.hc[2 * i + 1] = c23;
   }
+  if (m.hcm && K.htm) {  // tangent tables of the DLM order
+    for (int i = tid; i < S.nvx - 1; i += nthr) {
+      double2 c01, c23;
+      hermite_coeffs(K.htm[(size_t)slot * S.nvx + i], K.htm[(size_t)slot * S.nvx + i + 1], S.dv, c01, c23);
+      m.hcm[2 * i] = c01;
+      m.hcm[2 * i + 1] = c23;
+    }
+    for (int i = tid; i < kNXi2; i += nthr) m.Wm[i] = K.Wm[(size_t)slot * kNXi2 + i];
+  }
   if (with_taps) {
     for (int i = tid; i < S.ntaps[0]; i += nthr) m.taps[0][i] = S.taps[0][i];
     for (int i = tid; i < S.ntaps[1]; i += nthr) m.taps[1][i] = S.taps[1][i];
   }
   for (int i = tid; i < S.n_angles; i += nthr) { m.cosa[i] = S.cos_sa[i]; m.wsa[i] = S.w_sa[i]; }
-  T.zp = m.zp; T.W = m.W; T.ht = m.ht; T.hc = m.hc; T.nvx = S.nvx;
+  T.zp = m.zp; T.W = m.W; T.ht = m.ht; T.hc = m.hc; T.hcm = m.hcm; T.Wm = m.Wm; T.nvx = S.nvx;
   T.vx0 = S.vx0; T.dv = S.dv; T.idv = 1.0 / S.dv; T.vxlast = S.vx0 + (S.nvx - 1) * S.dv;
 }
 
@@ -314,14 +515,17 @@ __device__ __forceinline__ void loss_point(int method, double d, double t, doubl
 //   MODE 1: + masked loss sums + adjoint -> grad      (LossFunction.vg_loss)
 //   MODE 2: + per-lineout sums, theory denominator, sqdev arrays (LossFunction.array_loss)
 // ------------------------------------------------------------------------------------------
-template <int NI, int MODE>
-__global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCall K, int f0, int nfeat,
+template <int NI, int MODE, bool WM = false>
+__global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCall K, int f0, int nfeat, int flags,
                                                            const uint8_t* __restrict__ gmask, double* __restrict__ grad) {
+  // flags bit 0: add to grad instead of overwriting it (second launch of a feature-split call);
+  //       bit 1: k_s cache present in LDS
+  const bool accumulate = flags & 1, use_ks = flags & 2;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int half = tid >> 8, ht = tid & (kHalf - 1), lane = tid & 63, hw = (tid >> 6) & 3;
   const int f = f0 + half;  // feature of this half (wavefront-uniform)
   extern __shared__ __align__(16) unsigned char smem[];
-  const Smem m = carve(smem, S, nfeat);
+  const Smem m = carve(smem, S, nfeat, WM, use_ks);
   Tables T;
   load_tables(m, S, K, S.shared_fe ? 0 : b, true, T);
 
@@ -340,7 +544,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   // ================= forward sweep over (gradient point, lambda strip, angle) =================
   // each thread owns strips of kStrip consecutive samples; the right neighbour's (xi_e, F) needed by the
   // finite difference along lambda (form_factor.py:258) is evaluated by the owner of the strip.
-  double* __restrict__ ksc = m.ksc + half * (S.npts + 2);  // k_s(lambda) of the current gradient point
+  double* __restrict__ ksc = use_ks ? m.ksc + half * (S.npts + 2) : nullptr;  // k_s(lambda) of the current gradient point
   for (int g = 0; g < G; ++g) {
     LineS<NI> L;
     {
@@ -348,9 +552,11 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       phys_from_lds<NI>(m.phys, p);
       make_lines_uniform<NI>(p, lam_shift, g, G, L);
     }
-    if (g > 0) __syncthreads();
-    for (int i = ht; i < npts; i += kHalf) ksc[i] = ks_eval(omgs[i], L.wpe2);  // angle independent (form_factor.py:218)
-    __syncthreads();
+    if (use_ks) {
+      if (g > 0) __syncthreads();
+      for (int i = ht; i < npts; i += kHalf) ksc[i] = ks_eval(omgs[i], L.wpe2);  // angle independent (form_factor.py:218)
+      __syncthreads();
+    }
     for (int c = 0; c < ppp; ++c) {
       const int j0 = kStrip * (ht + kHalf * c);
       // the frequency axis is read from global memory (L1/L2): the strip's first two samples once per
@@ -360,7 +566,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
         const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a] * invG);
         double ws = ws_first, wnext = ws_second;
         Base b0;
-        base_eval<NI>(ws, ksc[j0], ct, L, T, b0);
+        base_eval<NI>(ws, use_ks ? ksc[j0] : ks_eval(ws, L.wpe2), ct, L, T, b0);
         TSFF_UNROLL(TSFF_QUNROLL)
         for (int q = 0; q < kStrip; ++q) {
           const int j = j0 + q;
@@ -368,7 +574,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
           const double wsn = wnext;
           wnext = omgs[min(j + 2, npts - 1)];
           Base b1;
-          base_eval<NI>(wsn, ksc[min(j + 1, npts - 1)], ct, L, T, b1);
+          base_eval<NI>(wsn, use_ks ? ksc[min(j + 1, npts - 1)] : ks_eval(wsn, L.wpe2), ct, L, T, b1);
           xs[j] += wa * point_forward<NI>(ws, b0, b1, has_next, L, T);
           b0 = b1;
           ws = wsn;
@@ -545,7 +751,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
 
   // ================= reverse sweep: recompute each point, accumulate lineout-scalar adjoints =================
   constexpr int NPk = TSFF_NP(NI);
-  constexpr int NLB = 8 + 3 * NI;               // adjoint-carrying fields of LineS
+  constexpr int NLB = 9 + 3 * NI;               // adjoint-carrying fields of LineS
   double* gsum = m.red + 8 * kNP_MAX;           // [2][NPk] physical-parameter adjoints of the two features
   if (ht < NPk) gsum[half * NPk + ht] = 0.0;
   const int wv = tid >> 6;
@@ -557,7 +763,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       make_lines_uniform<NI>(p, lam_shift, g, G, L);
     }
     zero_lines<NI>(LB);
-    if (G > 1) {  // (with one gradient point the cache of the forward sweep is still valid)
+    if (use_ks && G > 1) {  // (with one gradient point the cache of the forward sweep is still valid)
       __syncthreads();
       for (int i = ht; i < npts; i += kHalf) ksc[i] = ks_eval(omgs[i], L.wpe2);
       __syncthreads();
@@ -569,7 +775,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
         const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a]);
         double ws = ws_first, wnext = ws_second;
         Base b0;
-        base_eval<NI>(ws, ksc[j0], ct, L, T, b0);
+        base_eval<NI>(ws, use_ks ? ksc[j0] : ks_eval(ws, L.wpe2), ct, L, T, b0);
         double cxe = 0.0, cF = 0.0;
         TSFF_UNROLL(TSFF_QUNROLL)
         for (int q = 0; q < kStrip; ++q) {
@@ -578,12 +784,12 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
           const double wsn = wnext;
           wnext = omgs[min(j + 2, npts - 1)];
           Base b1;
-          base_eval<NI>(wsn, ksc[min(j + 1, npts - 1)], ct, L, T, b1);
+          base_eval<NI>(wsn, use_ks ? ksc[min(j + 1, npts - 1)] : ks_eval(wsn, L.wpe2), ct, L, T, b1);
           BaseAdj ba;
           double xen, Fn;
-          point_reverse<NI>(ws, b0, b1, has_next, L, T, xs[j] * wa, ba, xen, Fn, LB);
+          point_reverse<NI, WM>(ws, b0, b1, has_next, L, T, xs[j] * wa, ba, xen, Fn, LB);
           ba.xe += cxe; ba.F += cF;
-          base_reverse<NI>(ct, b0, L, ba, LB);
+          base_reverse<NI, WM>(ct, b0, L, T, ba, LB);
           cxe = xen; cF = Fn;
           b0 = b1;
           ws = wsn;
@@ -591,7 +797,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
         if (j0 + kStrip < npts) {  // the strip's right neighbour receives the D-coupling of the last point
           BaseAdj ba;
           ba.k2 = ba.ik = ba.wd = 0.0; ba.xe = cxe; ba.F = cF;
-          base_reverse<NI>(ct, b0, L, ba, LB);
+          base_reverse<NI, WM>(ct, b0, L, T, ba, LB);
         }
       }
     }
@@ -602,6 +808,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       lb[0] = LB.wpe2; lb[1] = LB.wL; lb[2] = LB.kL; lb[3] = LB.ivTe; lb[4] = LB.a_e; lb[5] = LB.pref; lb[6] = LB.Ud; lb[7] = LB.Vd;
 #pragma unroll
       for (int s = 0; s < NI; ++s) { lb[8 + 3 * s] = LB.ixi[s]; lb[9 + 3 * s] = LB.a_i[s]; lb[10 + 3 * s] = LB.cs[s]; }
+      lb[NLB - 1] = LB.m;
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < NLB; ++k) {
@@ -616,6 +823,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
         LB.wpe2 = lb[0]; LB.wL = lb[1]; LB.kL = lb[2]; LB.ivTe = lb[3]; LB.a_e = lb[4]; LB.pref = lb[5]; LB.Ud = lb[6]; LB.Vd = lb[7];
 #pragma unroll
         for (int s = 0; s < NI; ++s) { LB.ixi[s] = lb[8 + 3 * s]; LB.a_i[s] = lb[9 + 3 * s]; LB.cs[s] = lb[10 + 3 * s]; }
+        LB.m = lb[NLB - 1];
         Phys<NI> p;
         phys_from_lds<NI>(m.phys, p);
         double pbar[NPk];
@@ -655,14 +863,15 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       gsum[o] = (gsum[o] - dot) / p.fsum;
       gsum[TSFF_P_ION0 + 4 * s + TSFF_ION_A] = 0.0;
     }
-    gsum[TSFF_P_M] = 0.0;
+    if (!WM) gsum[TSFF_P_M] = 0.0;
   }
   __syncthreads();
   if (tid < NPk) {
     const double xv = xpar[tid];
     double v = gsum[tid] * S.p_scale[tid];
     if (S.p_sig[tid]) { const double sg = sigmoid(xv); v *= sg * (1.0 - sg); }
-    grad[(size_t)b * NPk + tid] = gmask[tid] ? v : 0.0;
+    v = gmask[tid] ? v : 0.0;
+    grad[(size_t)b * NPk + tid] = accumulate ? grad[(size_t)b * NPk + tid] + v : v;
   }
 }
 
@@ -688,7 +897,7 @@ __global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, in
                                                           int npts, double* __restrict__ P) {
   const int b = blockIdx.x, tid = threadIdx.x;
   extern __shared__ __align__(16) unsigned char smem[];
-  const Smem m = carve(smem, S, 1);
+  const Smem m = carve(smem, S, 1, false, false);
   Tables T;
   load_tables(m, S, K, S.shared_fe ? 0 : b, false, T);
   Phys<NI> p;

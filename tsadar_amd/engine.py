@@ -36,6 +36,19 @@ def zprime_tables(xi2):
     return np.interp(xi2, rd[:, 0], rd[:, 1]), np.interp(xi2, im[:, 0], im[:, 1])
 
 
+def log_ratio_table(xi1, xi2):
+    """Lg[q][i] = log|(gav + gdif/2) / (gav - gdif/2)| of ratintn.ratcen (ratintn.py:41-49) for
+    g = xi1 - xi2[q], i = 0..1021 (the last interval is dropped, :21), zero-padded to 1024 columns.
+    With it the Re(chi_e) table of a distribution function is two matrix-vector products."""
+    g = xi1[None, :] - xi2[:, None]
+    gdif = g[:, 1:-1] - g[:, 0:-2]
+    gav = 0.5 * (g[:, 1:-1] + g[:, 0:-2])
+    assert np.all(np.abs(gdif) >= 1.0e-4 * np.abs(gav)), "ratcen's small-gdif branch would trigger"
+    out = np.zeros((xi2.size, xi1.size))
+    out[:, : xi1.size - 2] = np.log(np.abs((gav + 0.5 * gdif) / (gav - 0.5 * gdif)))
+    return out
+
+
 def wavelength_axis_nm(lam_range, npts):
     """The axis the reference hands to the IRF: lamAxis = squeeze(2 pi c / omgs) * 1e7
     (form_factor.py:132-135, 293; generate_spectra.py:163, 191)."""
@@ -139,6 +152,8 @@ class Engine:
         zr, zi = zprime_tables(xi2)
         for name, arr in (("xi1", xi1), ("xi2", xi2), ("zprime_re", zr), ("zprime_im", zi)):
             a, p = _as_c(arr, np.float64); keep.append(a); setattr(c, name, p)
+        if fe_mode != L.FE_SHARED:
+            a, c.lg_table = _as_c(log_ratio_table(xi1, xi2), np.float64); keep.append(a)
 
         # instrument response
         phys = other["PhysParams"]
