@@ -125,12 +125,15 @@ def main():
     ap.add_argument("--ppp", type=int, default=1, help="points per pixel (1 -> 1024 wavelength points per feature)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="lineouts of the CPU baseline (0 = skip)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: forward-only (not the headline metric)")
+    ap.add_argument("--dlm", action="store_true",
+                    help="variant: the reference's canonical active set {Te, ne, m, amp1, amp2, lam} with a per-lineout "
+                         "super-Gaussian order m ~ U(2, 3.5) (per-lineout W tables; not the headline metric)")
     args = ap.parse_args()
 
     from tsadar_amd import synthetic as S
 
     cpu_res = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_sample > 0 and not args.forward_only:
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_sample > 0 and not args.forward_only and not args.dlm:
         cpu_res = cpu_baseline(S.baseline_deck(points_per_pixel=args.ppp, batch_size=args.batch), args.batch, args.cpu_sample)
 
     import torch
@@ -147,7 +150,8 @@ def main():
         import torch.distributed as dist
 
     B = args.batch
-    cfg = S.baseline_deck(points_per_pixel=args.ppp, batch_size=B)
+    active = ("Te", "ne", "m", "amp1", "amp2", "lam") if args.dlm else S.ACTIVE
+    cfg = S.baseline_deck(points_per_pixel=args.ppp, batch_size=B, active=active)
     from tsadar_amd.calibration import sa_lookup
 
     sa = sa_lookup("P9")
@@ -156,9 +160,9 @@ def main():
 
     # synthetic inputs: each rank draws its own shard (seed offset by rank), data generated on the GPU
     rng = np.random.default_rng(S.SEED + rank)
-    truth = S.draw_params(cfg, B, rng)
+    truth = S.draw_params(cfg, B, rng, dlm=args.dlm)
     batch = S.make_batch(eng, truth, rng)
-    guess = S.draw_params(cfg, B, rng)
+    guess = S.draw_params(cfg, B, rng, dlm=args.dlm)
     X = eng.dev(guess.to_matrix())
     gmask = guess.grad_mask()
     act = torch.tensor([s for _, s in guess.slots.active_leaves], device=dev)
@@ -224,15 +228,15 @@ def main():
     # profiles/r01_traffic.json, produced by scripts/profile_round.sh on the same workload
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tfile) and not args.forward_only:
+    if os.path.exists(tfile) and not args.forward_only and not args.dlm:
         tj = json.load(open(tfile))
         if tj.get("B") == B and tj.get("ppp") == args.ppp:
             traffic = tj["hbm_bytes_per_launch"]
     abytes = algorithmic_bytes(eng.NP, with_noise=False) if not args.forward_only else (eng.NP * 8 + 16 + 2 * 1024 * 8)
     achieved = B * abytes / kavg_s / 1e9
     res = {
-        "metric": "spectra/sec (fwd+grad), 1024-lambda EPW+IAW form factor, batch 4096" if not args.forward_only
-        else "spectra/sec (forward only), 1024-lambda EPW+IAW form factor",
+        "metric": ("spectra/sec (fwd+grad), 1024-lambda EPW+IAW form factor, batch 4096" if not args.forward_only
+                   else "spectra/sec (forward only), 1024-lambda EPW+IAW form factor") + (" [DLM variant: per-lineout f_e]" if args.dlm else ""),
         "value": value,
         "unit": "spectra/s",
         "n_gpus": world,

@@ -426,3 +426,57 @@ def test_errors_are_reported_not_swallowed(torch_mod):
 
     with pytest.raises(NotImplementedError, match="Unknown spectype"):
         ThomsonScatteringDiagnostic(cfg, sa)
+
+
+def _dist_rank(rank, world, port, out):
+    """One rank of the 2-process rehearsal: real engine on the (shared) GPU, gloo collectives."""
+    import os
+    import sys
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), TSFF_DIST_BACKEND="gloo", TSFF_FORCE_DEVICE="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+
+    from tsadar_amd import ThomsonParams, distributed as D, tree
+    from tsadar_amd.loss_function import LossFunction
+
+    z = np.load(os.path.join(root, "tests/golden/oracle_fit_b4.npz"))
+    B = 4
+    D.init_from_env()
+    cfg = decks.deck_fit(active=("Te", "ne", "Ti", "Va", "lam", "amp1"))
+    lo, hi = D.shard_bounds(B, world, rank)
+    full = {k: z[k] for k in ("e_data", "i_data", "e_amps", "i_amps", "noise_e", "noise_i")}
+    local = {k: v[lo:hi] for k, v in full.items()}
+    lf = LossFunction(cfg, util.sa_fit(hi - lo), full, distributed=True)  # norms from the global sample, as loops.py:133
+    tp = ThomsonParams(cfg["parameters"], B, batch=True, activate=True)
+    tp.X[:] = z["X"]
+    diff, _ = tree.partition(tp)
+    x0, lf.unravel_weights = tree.ravel_pytree(diff)
+    tpl = ThomsonParams(cfg["parameters"], hi - lo, batch=True, activate=True)
+    tpl.X[:] = tp.X[lo:hi]
+    value, flat = lf.vg_loss(x0, tree.StaticParams(tpl), local)
+    np.save(os.path.join(out, f"r{rank}.npy"), np.concatenate([[value], flat]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_fit_step_on_gpu(torch_mod, tmp_path):
+    """two ranks (sharing this box's single GPU, gloo transport) evaluate their shards with the
+    HIP engine and all-reduce [loss sums | gradient]; both hold the full-batch loss and gradient of the
+    committed fixture."""
+    import socket
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dist_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    np.testing.assert_array_equal(r0, r1)
+    z = np.load("tests/golden/oracle_fit_b4.npz")
+    gref = z["grad"][:, [0, 1, 2, 4, 5, 3]].T.reshape(-1)
+    assert abs(r0[0] - float(z["loss"])) < 1e-9 * abs(float(z["loss"]))
+    assert np.max(np.abs(r0[1:] - gref)) < 1e-7 * np.max(np.abs(gref))

@@ -21,6 +21,10 @@ def init_from_env(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs for a one-GPU box (several ranks sharing device 0 over gloo); never set in production
+    backend = backend or os.environ.get("TSFF_DIST_BACKEND")
+    if "TSFF_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["TSFF_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

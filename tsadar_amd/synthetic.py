@@ -82,7 +82,7 @@ _SLOT = dict(Te=L.P_TE, ne=L.P_NE, Ti=L.P_ION0 + L.ION_TI, lam=L.P_LAM, amp1=L.P
              amp3=L.P_AMP3, Va=L.P_VA)
 
 
-def draw_params(cfg: dict, B: int, rng: np.random.Generator, activate: bool = True) -> ThomsonParams:
+def draw_params(cfg: dict, B: int, rng: np.random.Generator, activate: bool = True, dlm: bool = False) -> ThomsonParams:
     """B lineouts with physical values uniform in RANGES (mapped through the exact inverse of the
     activation, so the physical value is the drawn one)."""
     tp = ThomsonParams(cfg["parameters"], B, batch=True, activate=activate)
@@ -91,6 +91,10 @@ def draw_params(cfg: dict, B: int, rng: np.random.Generator, activate: bool = Tr
         s = _SLOT[name]
         u = (rng.uniform(lo, hi, B) - sm.shift[s]) / sm.scale[s]
         tp.X[:, s] = np.log(u / (1 - u)) if sm.sigmoid[s] else u
+    if dlm:  # per-lineout super-Gaussian order (tests/test_inverse/test_1d_random.py:33)
+        u = (rng.uniform(2.0, 3.5, B) - sm.shift[L.P_M]) / sm.scale[L.P_M]
+        u = np.clip(u, 1e-6, 1 - 1e-6)
+        tp.X[:, L.P_M] = np.log(u / (1 - u)) if sm.sigmoid[L.P_M] else u
     return tp
 
 
