@@ -140,6 +140,11 @@ void tsff_destroy(tsff_handle *h);
 const char *tsff_last_error(const tsff_handle *h); /* h == NULL: last tsff_create failure */
 int tsff_abi_version(void);
 int tsff_set_stream(tsff_handle *h, void *hip_stream);
+/* options.  TSFF_OPT_DENOM_MODE: denominators of the l1/l2 functionals in tsff_loss_grad -- 0 (default):
+ * constants folded into `weights` (LossFunction.__loss__, loss_function.py:364-373); 2: |data| + 1e-10 per sample
+ * (LossFunction._loss_for_hess_fn_, loss_function.py:173-188, the loss whose Hessian gives the fit uncertainties). */
+enum { TSFF_OPT_DENOM_MODE = 1 };
+int tsff_set_option(tsff_handle *h, int32_t key, int32_t value);
 /* make sure the workspace holds B lineouts (calls grow it lazily; not inside graph capture) */
 int tsff_reserve(tsff_handle *h, int32_t B);
 

@@ -305,6 +305,40 @@ def loss(cfg, sa, normed, batch, i_norm, e_norm, activate=True, fe_batch=None):
     return cfg["data"]["ion_loss_scale"] * i_err + e_err, ThryE, ThryI
 
 
+def hessian_loss(cfg, sa, normed, batch, activate=True):
+    """``LossFunction._loss_for_hess_fn_`` (loss_function.py:173-188): denominators |data| + 1e-10, sum reduce,
+    i_error + e_error (e_error halved when both EPW ranges are fitted, :262-264)."""
+    ThryE, ThryI, lamE, lamI = ts_diag(cfg, sa, normed, batch, activate)
+    ext = cfg["other"]["extraoptions"]
+    iaw, blue, red = orc.fit_masks(cfg, lamE.detach().numpy(), lamI.detach().numpy())
+    ed, idt = _t(batch["e_data"]), _t(batch["i_data"])
+    fe = torch.square(ed - ThryE) / (torch.abs(ed) + 1e-10)
+    fi = torch.square(idt - ThryI) / (torch.abs(idt) + 1e-10)
+    i_err = fi[torch.as_tensor(iaw)].sum() if ext["fit_IAW"] else torch.zeros((), dtype=DT)
+    e_err = torch.zeros((), dtype=DT)
+    if ext["fit_EPWb"]:
+        e_err = e_err + fe[torch.as_tensor(blue)].sum()
+    if ext["fit_EPWr"]:
+        e_err = e_err + fe[torch.as_tensor(red)].sum()
+        if ext["fit_EPWb"]:
+            e_err = e_err * 0.5
+    return i_err + e_err
+
+
+def hessian(cfg, sa, normed_np, batch, names, activate=True):
+    """Dense Hessian [P, P] of hessian_loss w.r.t. the leaves ``names`` of a ONE-lineout batch (double backward)."""
+    base = {k: _t(v).clone() for k, v in normed_np.items()}
+
+    def f(vec):
+        nm = dict(base)
+        for i, k in enumerate(names):
+            nm[k] = vec[i:i + 1]
+        return hessian_loss(cfg, sa, nm, batch, activate)
+
+    x0 = torch.cat([base[k].reshape(1) for k in names])
+    return torch.autograd.functional.hessian(f, x0).numpy()
+
+
 def value_and_grad(cfg, sa, normed_np, batch, i_norm, e_norm, names, activate=True, fe_batch=None):
     """(loss, {name: dloss/d normed[name]  [B]}, ThryE, ThryI) by reverse-mode autodiff."""
     normed = {k: _t(v).clone() for k, v in normed_np.items()}

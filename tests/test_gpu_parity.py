@@ -525,3 +525,34 @@ def test_inverse_round_trip_like_reference(torch_mod):
     for sp, k in (("electron", "Te"), ("electron", "ne"), ("electron", "m"), ("general", "amp1"), ("general", "amp2"), ("general", "lam")):
         np.testing.assert_allclose(learned[sp][k], truth[sp][k], atol=0, rtol=0.1, err_msg=f"{sp}.{k} (loss {res['fun']:.3e})")
     assert res["fun"] < 1e-4  # (the reference asserts only the parameters)
+
+
+def test_hessian_for_sigmas(torch_mod):
+    """LossFunction.h_loss_wrt_params (central differences of the HIP gradient of the
+    reference's Hessian loss) vs the double-backward Hessian of the oracle twin, in the nested layout
+    postprocess.get_sigmas reads."""
+    from oracle import tsadar_oracle_torch as ot
+    from tsadar_amd import ThomsonParams
+    from tsadar_amd.loss_function import LossFunction
+
+    active = ("Te", "ne", "Ti", "lam", "amp1")
+    names = ["Te", "ne", "Ti_1", "lam", "amp1"]  # ravel order
+    keys = [("electron", "Te"), ("electron", "ne"), ("ion-1", "Ti"), ("general", "lam"), ("general", "amp1")]
+    cfg = decks.deck_fit(active=active)
+    B = 2
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B, seed=53)
+    lf = LossFunction(cfg, sa, batch)
+    tp = ThomsonParams(cfg["parameters"], B, batch=True, activate=True)
+    tp.X[:] = util.normed_to_matrix(normed, 1)
+    hess = lf.h_loss_wrt_params(tp, batch)
+    assert set(hess) == {"electron", "ion-1", "general"} and hess["electron"]["Te"]["general"]["lam"].shape == (B, B)
+    for b in range(B):
+        nb = {k: v[b:b + 1] for k, v in normed.items()}
+        bb = {k: np.asarray(v)[b:b + 1] for k, v in batch.items()}
+        Ho = ot.hessian(cfg, util.sa_fit(1), nb, bb, names)
+        Hg = np.array([[hess[s1][k1][s2][k2][b, b] for (s2, k2) in keys] for (s1, k1) in keys])
+        assert np.max(np.abs(Hg - Ho)) < 2e-4 * np.max(np.abs(Ho)), (b, Hg, Ho)
+        # the quantity postprocess.get_sigmas derives from it
+        sg = np.sign(np.diag(np.linalg.inv(Hg))) * np.sqrt(np.abs(np.diag(np.linalg.inv(Hg))))
+        so = np.sign(np.diag(np.linalg.inv(Ho))) * np.sqrt(np.abs(np.diag(np.linalg.inv(Ho))))
+        np.testing.assert_allclose(sg, so, rtol=5e-3)

@@ -24,6 +24,7 @@ ION_TI, ION_Z, ION_A, ION_FRACT = range(4)
 FE_SHARED, FE_PER_LINEOUT, FE_DLM = range(3)
 LOSS_METHODS = {"l2": 0, "l1": 1, "log-cosh": 2, "poisson": 3}
 FEATURE_ELE, FEATURE_ION = 0, 1
+OPT_DENOM_MODE = 1
 
 
 def n_params(n_ion: int) -> int:
@@ -82,6 +83,7 @@ _SIGNATURES = {
     "tsff_destroy": (None, [_vp]),
     "tsff_last_error": (C.c_char_p, [_vp]),
     "tsff_set_stream": (C.c_int, [_vp, _vp]),
+    "tsff_set_option": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "tsff_reserve": (C.c_int, [_vp, C.c_int32]),
     "tsff_get_axes": (C.c_int, [_vp, c_double_p, c_double_p]),
     "tsff_chi_table": (C.c_int, [_vp, _vp, C.c_int32, _vp]),

@@ -56,6 +56,7 @@ struct KCall {
   double* lpart;         // [B][3]
   double wts[3];
   int B;
+  int denom_mode;        // MODE 1 only: 0 constant denominators (folded into wts), 2: |data| + 1e-10 per sample
 };
 
 // ------------------------------------------------------------------------------------------
@@ -660,6 +661,11 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
         if (mk & 2) { s1 += e; sq += e; }
         if (K.sqdev[f]) K.sqdev[f][(size_t)b * TSFF_NBINS + pb] = sq;
       } else {
+        if (K.denom_mode == 2 && (S.loss_method == TSFF_LOSS_L2 || S.loss_method == TSFF_LOSS_L1)) {
+          const double iden = 1.0 / (fabs(d) + 1e-10);  // loss_function.py:183 (_loss_for_hess_fn_)
+          e *= iden;
+          det *= iden;
+        }
         double w = 0.0;
         if (mk & 1) { s0 += e; w += (f == TSFF_FEATURE_ELE ? K.wts[1] : K.wts[0]); }
         if (mk & 2) { s1 += e; w += K.wts[2]; }

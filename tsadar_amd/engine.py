@@ -371,6 +371,10 @@ class Engine:
         L.check(self.lib, self.h, rc)
         return sums, sqe, sqi, E, I
 
+    def set_denominator_mode(self, mode: int):
+        """0: constant denominators (fit loss); 2: |data| + 1e-10 per sample (the reference's Hessian loss)."""
+        L.check(self.lib, self.h, self.lib.tsff_set_option(self.h, L.OPT_DENOM_MODE, int(mode)))
+
     def enable_timing(self, ring: int = 256):
         """Record one HIP event pair around every main-kernel launch (ring of ``ring`` launches)."""
         L.check(self.lib, self.h, self.lib.tsff_enable_timing(self.h, int(ring)))

@@ -130,5 +130,42 @@ class LossFunction:
         sqdev = {"ele": sqe.cpu().numpy(), "ion": sqi.cpu().numpy()}
         return total, sqdev, E.cpu().numpy(), I.cpu().numpy(), weights()
 
-    def h_loss_wrt_params(self, weights, batch):
-        raise NotImplementedError("Hessian of the loss (calc_sigmas) is not implemented yet")
+    def h_loss_wrt_params(self, weights: ThomsonParams, batch: Dict, step: float = 1e-7):
+        """Hessian of the reference's ``_loss_for_hess_fn_`` (loss_function.py:173-188: denominators |data| + 1e-10,
+        sum reduce, i_error + e_error) w.r.t. the trainable normalised leaves, in the nested layout
+        ``get_sigmas`` reads (postprocess.py:188-251): ``hess[species][key][species2][key2]`` is a [B, B] matrix whose
+        diagonal holds the per-lineout second derivatives (lineouts do not couple).
+
+        The reference differentiates twice with JAX; here the analytic gradient of the HIP adjoint is
+        central-differenced: 2 * P gradient evaluations of the whole batch (every lineout is perturbed at once).
+        The step is small on purpose: JAX's second derivative of the piecewise-linear table lookups (Z', W) is
+        zero inside a table cell, and a step of 1e-7 (normalised units) keeps nearly every sample inside its
+        cell, so the difference quotient reproduces that convention (2e-6 relative against double-backward
+        autodiff of the oracle; with 1e-4 the curvature of the tables leaks in and entries change sign)."""
+        eng = self.ts_diag.engine(weights.activate)
+        X = weights.to_matrix()
+        B = X.shape[0]
+        db = self._device_batch(eng, batch, B)
+        c = 0.5 if (eng.fit_blue and eng.fit_red) else 1.0
+        w = np.array([1.0 if eng.fit_iaw else 0.0, c if eng.fit_blue else 0.0, c if eng.fit_red else 0.0])
+        leaves = weights.slots.active_leaves
+        act = [s for _, s in leaves]
+        gm = weights.grad_mask()
+        H = np.zeros((B, len(act), len(act)))
+        eng.set_denominator_mode(2)
+        try:
+            for k, s in enumerate(act):
+                Xp, Xm = X.copy(), X.copy()
+                Xp[:, s] += step
+                Xm[:, s] -= step
+                gp = eng.loss_grad(Xp, db, w, gm)[1][:, act].cpu().numpy()
+                gn = eng.loss_grad(Xm, db, w, gm)[1][:, act].cpu().numpy()
+                H[:, :, k] = (gp - gn) / (2 * step)
+        finally:
+            eng.set_denominator_mode(0)
+        H = 0.5 * (H + np.transpose(H, (0, 2, 1)))
+        hess = {}
+        for a, ((sp1, k1), _) in enumerate(leaves):
+            for b_, ((sp2, k2), _) in enumerate(leaves):
+                hess.setdefault(sp1, {}).setdefault(k1, {}).setdefault(sp2, {})[k2] = np.diag(H[:, a, b_])
+        return hess
