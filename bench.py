@@ -222,6 +222,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    fp64_measured = eng.fp64_fma_peak_tflops()  # micro-benchmark on this very device, outside the timed region
 
     kavg_s = float(np.mean(ktimes)) * 1e-3 if ktimes.size else float("nan")
     # HBM bytes per launch from the PMC passes of this round (rocprofv3 --pmc cannot run inside bench.py):
@@ -280,6 +281,8 @@ def main():
             "unit": "TFLOP/s",
             "frac": B * FLOP_PER_SPECTRUM / kavg_s / FP64_PEAK,
             "algorithmic_flop_per_spectrum": FLOP_PER_SPECTRUM,
+            "peak_measured_fma": fp64_measured,
+            "frac_of_measured": B * FLOP_PER_SPECTRUM / kavg_s / 1e12 / fp64_measured,
         },
     }
     if pcie_value is not None:

@@ -199,6 +199,10 @@ int tsff_array_loss(tsff_handle *h, const double *params, const double *fe, cons
 int tsff_enable_timing(tsff_handle *h, int32_t ring);
 int tsff_kernel_times(tsff_handle *h, float *ms, int32_t max_n, int32_t *n_out);
 
+/* micro-benchmark: sustained FP64 vector FMA rate of this device in TFLOP/s (the roof the path is bound by;
+ * AMD's datasheet figure for MI355X is 78.6).  Synchronous. */
+int tsff_fp64_fma_peak(tsff_handle *h, double *tflops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "tsff_array_loss": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "tsff_enable_timing": (C.c_int, [_vp, C.c_int32]),
     "tsff_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
+    "tsff_fp64_fma_peak": (C.c_int, [_vp, C.POINTER(C.c_double)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -940,6 +940,24 @@ __global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, in
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_fma_peak: micro-benchmark of the FP64 vector FMA rate (the roof this path is bound by): 16 independent
+// accumulators per lane, `iters` x 16 fused multiply-adds, enough wavefronts to fill every SIMD.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_fma_peak(double* __restrict__ out, int iters, double a, double b) {
+  double acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (double)(threadIdx.x + i) * 1e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(acc[i], a, b);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i];
+  out[(size_t)blockIdx.x * kThreads + threadIdx.x] = s;
+}
+
 }  // namespace tsff
 
 #include "tsff_api.inc"

@@ -375,6 +375,12 @@ class Engine:
         """0: constant denominators (fit loss); 2: |data| + 1e-10 per sample (the reference's Hessian loss)."""
         L.check(self.lib, self.h, self.lib.tsff_set_option(self.h, L.OPT_DENOM_MODE, int(mode)))
 
+    def fp64_fma_peak_tflops(self) -> float:
+        """Measured FP64 vector FMA rate of this device (micro-benchmark, TFLOP/s)."""
+        v = C.c_double()
+        L.check(self.lib, self.h, self.lib.tsff_fp64_fma_peak(self.h, C.byref(v)))
+        return float(v.value)
+
     def enable_timing(self, ring: int = 256):
         """Record one HIP event pair around every main-kernel launch (ring of ``ring`` launches)."""
         L.check(self.lib, self.h, self.lib.tsff_enable_timing(self.h, int(ring)))
