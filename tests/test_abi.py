@@ -25,7 +25,7 @@ def lib():
 def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(tsff_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(tsff_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol(lib):
