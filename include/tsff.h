@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TSFF_ABI_VERSION 2
+#define TSFF_ABI_VERSION 3
 
 /* ---- parameter slots of one lineout: params[b][TSFF_NP(n_ion)] (normalised leaves of the
  * reference's ThomsonParams pytree, core/modules/ts_params.py:49-60,395-420,253-262) ---------- */
@@ -107,13 +107,15 @@ typedef struct tsff_config {
    * per-lineout W tables are then two matrix-vector products with this constant table. */
   const double *lg_table;
 
-  /* instrument response (irf.py:50-132): Gaussian taps g[d], y[j] = sum_d g[d] x[j-d],
-   * d = tap_dmin .. tap_dmin + n_taps - 1 (the reference's "same" alignment) */
+  /* instrument response + binning (irf.py:50-132) as ONE set of bin-averaged taps per feature:
+   *   ybin[p] = sum_{s < n_taps} taps[s] * x[p * ppp + tap_off + s],   ppp = npts / 1024,
+   * i.e. taps = (1/ppp) * (Gaussian of irf.py:66-72 / 110-114, in the reference's "same" alignment) convolved
+   * with a ppp-wide box (irf.py:74,124); see DESIGN.md section 3 and engine.binned_taps(). */
   int32_t n_taps_ele;
-  int32_t tap_dmin_ele;
+  int32_t tap_off_ele;
   const double *taps_ele;
-  int32_t n_taps_ion; /* 0 <=> spect_stddev_ion == 0 (irf.py:85: ThryI = modlI, npts must be 1024) */
-  int32_t tap_dmin_ion;
+  int32_t n_taps_ion; /* 0 <=> spect_stddev_ion == 0 (irf.py:85: ThryI = modlI), not implemented */
+  int32_t tap_off_ion;
   const double *taps_ion;
   int32_t norm; /* other.PhysParams.norm; only 0 is implemented */
 

@@ -96,3 +96,23 @@ def test_scattering_angles():
 
     with pytest.raises(NotImplementedError):
         sa_lookup("nope")
+
+
+def test_binned_taps_equal_convolve_then_bin():
+    """engine.binned_taps folds the ppp-sample bin average into the IRF taps: identical (to rounding) to
+    np.convolve(x, g, 'same').reshape(1024, -1).mean(axis=1)."""
+    rng = np.random.default_rng(1)
+    for ppp, rngE, sd in ((1, [400, 700], 1.3), (2, [400, 700], 1.3), (5, [525.75, 527.25], 0.015)):
+        npts = 1024 * ppp
+        lam = E.wavelength_axis_nm(rngE, npts)
+        x = rng.random(npts) ** 6
+        origin = (lam.max() + lam.min()) / 2
+        g = (1.0 / (sd * np.sqrt(2 * np.pi))) * np.exp(-((lam - origin) ** 2) / (2 * sd**2))
+        ref = np.convolve(x, g, "same").reshape(1024, -1).mean(axis=1)
+        taps, dmin = E.gaussian_taps(lam, sd, 12.0)
+        hb, off = E.binned_taps(taps, dmin, ppp)
+        assert hb.size == taps.size + ppp - 1
+        pad = hb.size + abs(off) + ppp
+        xp = np.concatenate([np.zeros(pad), x, np.zeros(pad)])
+        y = np.array([np.dot(hb, xp[pad + p * ppp + off: pad + p * ppp + off + hb.size]) for p in range(1024)])
+        assert np.max(np.abs(y - ref)) < 1e-13 * ref.max()

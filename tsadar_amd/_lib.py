@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsff.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_ION = 4
 NBINS = 1024
 NXI1 = 1024
@@ -59,10 +59,10 @@ class TsffConfig(C.Structure):
         ("zprime_im", c_double_p),
         ("lg_table", c_double_p),
         ("n_taps_ele", C.c_int32),
-        ("tap_dmin_ele", C.c_int32),
+        ("tap_off_ele", C.c_int32),
         ("taps_ele", c_double_p),
         ("n_taps_ion", C.c_int32),
-        ("tap_dmin_ion", C.c_int32),
+        ("tap_off_ion", C.c_int32),
         ("taps_ion", c_double_p),
         ("norm", C.c_int32),
         ("ele_filter", c_double_p),

@@ -28,9 +28,10 @@ struct KStatic {
   const double* xi1;         // [1024]
   const double* xi2;         // [1640]
   const double* taps[2];
-  int ntaps[2];
-  int dmin[2];
+  int ntaps[2];              // length of the bin-averaged IRF taps hb
+  int toff[2];               // ybin[p] = sum_s hb[s] x[p * ppp + toff + s]
   int halo;                  // zero padding on both sides of the LDS spectrum buffers (>= every |tap offset|)
+  int halo_bins;             // the same for the per-bin adjoint buffer
   const uint8_t* mask[2];    // [1024]
   const double* p_scale;
   const double* p_shift;
@@ -379,6 +380,7 @@ __host__ __device__ inline size_t smem_doubles(const KStatic& S, int nfeat, bool
   size_t n = 2 * (size_t)(kNXi2 + S.nvx) + kNXi2 + 4 * (size_t)S.nvx;                    // zp, ht, W, hc
   if (with_m) n += 4 * (size_t)S.nvx + kNXi2;                                               // hcm, Wm
   n += (size_t)nfeat * ((size_t)S.npts + 2 * (size_t)S.halo);                               // spectrum buffers
+  n += (size_t)nfeat * ((size_t)TSFF_NBINS + 2 * (size_t)S.halo_bins);                      // per-bin adjoint buffers
   if (with_ks) n += (size_t)nfeat * ((size_t)S.npts + 2);                                   // k_s cache
   n += S.ntaps[0] + S.ntaps[1] + 2 * (size_t)S.n_angles + 11 * kNP_MAX + 66;                // taps, angles, phys, scratch
   return n;
@@ -390,11 +392,11 @@ __device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int
   m.ht = m.zp + kNXi2;
   m.W = reinterpret_cast<double*>(m.ht + S.nvx);
   double* p = m.W + kNXi2;
-  // one buffer per feature holds, in turn, the model spectrum x, the adjoint of the binned spectrum and the
-  // adjoint of x; `halo` zeros on both sides so the convolutions need no bounds checks
+  // one buffer per feature holds the model spectrum x and later its adjoint, another the adjoint of the binned
+  // spectrum; zero halos on both sides so the convolutions need no bounds checks
   m.x[0] = p; p += (size_t)nfeat * (S.npts + 2 * S.halo);
   m.x[1] = nullptr;
-  m.yb[0] = nullptr;
+  m.yb[0] = p; p += (size_t)nfeat * (TSFF_NBINS + 2 * S.halo_bins);
   m.yb[1] = nullptr;
   m.hc = reinterpret_cast<double2*>(p); p += 4 * (size_t)S.nvx;
   m.hcm = nullptr; m.Wm = nullptr;
@@ -539,7 +541,10 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   // (pointer arithmetic on the LDS base, not a runtime-indexed pointer array: keeps ds_* addressing)
   const int H = S.halo;
   double* __restrict__ xs = m.x[0] + half * (S.npts + 2 * H) + H;
+  const int Hb = S.halo_bins;
+  double* __restrict__ ybs = m.yb[0] + half * (TSFF_NBINS + 2 * Hb) + Hb;
   for (int i = ht - H; i < npts + H; i += kHalf) xs[i] = 0.0;
+  for (int i = ht - Hb; i < TSFF_NBINS + Hb; i += kHalf) ybs[i] = 0.0;
   __syncthreads();
 
   // ================= forward sweep over (gradient point, lambda strip, angle) =================
@@ -592,33 +597,21 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   __syncthreads();
 
   // ================= IRF convolution ("same"), bin average, normalisation =================
-  const int nt = S.ntaps[f], dmin = S.dmin[f], dmax = dmin + nt - 1;
+  // the host folds the bin average into the taps: hb[s] = (1/ppp) sum_jj g[jj - s + nt - 1], so that
+  // ybin[p] = sum_s hb[s] x[p ppp + toff + s]  (irf.py:72-74 / 114,124 in one pass; zero halo -> no bounds checks)
+  const int nh = S.ntaps[f], toff = S.toff[f];
   const double* __restrict__ taps = m.taps[0] + (f == TSFF_FEATURE_ELE ? 0 : S.ntaps[0]);
-  const double invp = 1.0 / (double)ppp;
   double ybin[4] = {0.0, 0.0, 0.0, 0.0};
   {
-    // y[j] = sum_t g[t] x[j - dmin - t]; the zero halo makes every index valid
-    const double* __restrict__ xp = xs - dmin;
-    if (ppp == 1) {  // one tap read feeds the thread's four bins
-      const double* __restrict__ x0 = xp + ht;
+    const double* __restrict__ x0 = xs + toff + ht * ppp;
+    const int rs = kHalf * ppp;
 #pragma unroll 4
-      for (int t = 0; t < nt; ++t) {
-        const double g = taps[t];
-        ybin[0] += g * x0[-t];
-        ybin[1] += g * x0[kHalf - t];
-        ybin[2] += g * x0[2 * kHalf - t];
-        ybin[3] += g * x0[3 * kHalf - t];
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double* __restrict__ x0 = xp + (ht + kHalf * r) * ppp;
-        double acc = 0.0;
-        for (int jj = 0; jj < ppp; ++jj)
-#pragma unroll 4
-          for (int t = 0; t < nt; ++t) acc += taps[t] * x0[jj - t];
-        ybin[r] = acc * invp;
-      }
+    for (int t = 0; t < nh; ++t) {  // one tap read feeds the thread's four bins
+      const double g = taps[t];
+      ybin[0] += g * x0[t];
+      ybin[1] += g * x0[rs + t];
+      ybin[2] += g * x0[2 * rs + t];
+      ybin[3] += g * x0[3 * rs + t];
     }
   }
   double M = ybin[0];
@@ -696,29 +689,26 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   sn = half_sum(sn, m.red, half, hw, lane);
   a1b = half_sum(a1b, m.red, half, hw, lane);
   a2b = half_sum(a2b, m.red, half, hw, lane);
-  // the spectrum buffer is dead (every bin has been formed, barriers above): reuse it for ybar [1024]
-  double* __restrict__ ybs = xs;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int pb = ht + kHalf * r;
     double yb = Tb[r] * Ap[r] * invM;
     if (pb == pstar) yb -= sn * invM;
-    ybs[pb] = yb * invp;
+    ybs[pb] = yb;
   }
   __syncthreads();
-  // ================= adjoint of the convolution: xbar_i = filt_i * sum_j ybar_j g[j-i] =================
+  // ================= adjoint of convolution + binning: xbar_i = filt_i sum_p ybar_p hb[i - p ppp - toff] =================
   if (ppp == 1) {
     double sx[4] = {0.0, 0.0, 0.0, 0.0};
-    const double* __restrict__ y0 = ybs + dmin + ht;
+    const double* __restrict__ y0 = ybs - toff + ht;
 #pragma unroll 4
-    for (int t = 0; t < nt; ++t) {
+    for (int t = 0; t < nh; ++t) {
       const double g = taps[t];
-      sx[0] += g * y0[t];
-      sx[1] += g * y0[kHalf + t];
-      sx[2] += g * y0[2 * kHalf + t];
-      sx[3] += g * y0[3 * kHalf + t];
+      sx[0] += g * y0[-t];
+      sx[1] += g * y0[kHalf - t];
+      sx[2] += g * y0[2 * kHalf - t];
+      sx[3] += g * y0[3 * kHalf - t];
     }
-    __syncthreads();  // every read of ybar is done before xbar overwrites the buffer
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = ht + kHalf * r;
@@ -727,31 +717,14 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       xs[i] = v * invG;
     }
   } else {
-    // generic points-per-pixel: xbar_i = sum_j ybar[j / ppp] g[j - i - dmin]; results are staged in registers
-    // chunk by chunk because ybar and xbar share the buffer
-    double keep[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int c = 0; c < ppp; ++c) {
-      double sv4[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = ht + kHalf * (4 * c + r);
-        const int jlo = max(0, i + dmin), jhi = min(npts - 1, i + dmax);
-        double sv = 0.0;
-        for (int j = jlo; j <= jhi; ++j) sv += taps[j - i - dmin] * ybs[j / ppp];
-        if (f == TSFF_FEATURE_ELE && S.filt) sv *= S.filt[i];
-        sv4[r] = sv * invG;
-      }
-      if (c == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) keep[r] = sv4[r];  // indices < 1024 still hold ybar: written last
-      } else {  // ybar only lives in [0, 1024): samples beyond it can be written at once
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xs[ht + kHalf * (4 * c + r)] = sv4[r];
-      }
+    for (int i = ht; i < npts; i += kHalf) {
+      const int q = i - toff;           // >= 0: toff = -dmax <= 0
+      int pb = q / ppp;
+      double sv = 0.0;
+      for (int t = q - pb * ppp; t < nh; t += ppp, --pb) sv += taps[t] * ybs[pb];
+      if (f == TSFF_FEATURE_ELE && S.filt) sv *= S.filt[i];
+      xs[i] = sv * invG;
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xs[ht + kHalf * r] = keep[r];
   }
   __syncthreads();
 

@@ -74,6 +74,18 @@ def gaussian_taps(lam_nm, stddev, cutoff_sigmas):
     return np.ascontiguousarray(g[lo : hi + 1]), lo - c
 
 
+def binned_taps(g, dmin, ppp):
+    """Fold the ppp-sample bin average (irf.py:74,124) into the taps of ``gaussian_taps``:
+    ybin[p] = (1/ppp) sum_jj y[p ppp + jj],  y[j] = sum_d g[d] x[j - d]  ==>  ybin[p] = sum_s hb[s] x[p ppp + off + s]
+    with hb[s] = (1/ppp) sum_jj g[jj - s + nt - 1] and off = -(dmin + nt - 1)."""
+    nt = g.size
+    hb = np.zeros(nt + ppp - 1)
+    for jj in range(ppp):
+        # s = jj - t + nt - 1 for t = 0..nt-1
+        hb[jj : jj + nt] += g[::-1]
+    return np.ascontiguousarray(hb / ppp), -(dmin + nt - 1)
+
+
 def _as_c(a, dtype):
     a = np.ascontiguousarray(a, dtype=dtype)
     ptr_t = L.c_double_p if dtype == np.float64 else L.c_uint8_p
@@ -162,12 +174,14 @@ class Engine:
         lamI = wavelength_axis_nm(other["lamrangI"], self.npts)
         if self.load_ele:
             t, d0 = gaussian_taps(lamE, float(phys["widIRF"]["spect_stddev_ele"]), irf_cutoff_sigmas)
+            t, off = binned_taps(t, d0, self.npts // L.NBINS)
             a, c.taps_ele = _as_c(t, np.float64); keep.append(a)
-            c.n_taps_ele, c.tap_dmin_ele = t.size, d0
+            c.n_taps_ele, c.tap_off_ele = t.size, off
         if self.load_ion and phys["widIRF"]["spect_stddev_ion"]:
             t, d0 = gaussian_taps(lamI, float(phys["widIRF"]["spect_stddev_ion"]), irf_cutoff_sigmas)
+            t, off = binned_taps(t, d0, self.npts // L.NBINS)
             a, c.taps_ion = _as_c(t, np.float64); keep.append(a)
-            c.n_taps_ion, c.tap_dmin_ion = t.size, d0
+            c.n_taps_ion, c.tap_off_ion = t.size, off
         filt = other.get("iawfilter", [0, 0, 0, 0])
         if self.load_ele and filt[0]:
             fb, fr = filt[3] - filt[2] / 2, filt[3] + filt[2] / 2
