@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void k_wgemm(const double* __restrict__ L
 // ------------------------------------------------------------------------------------------
 // shared helpers of the spectrum kernels
 // ------------------------------------------------------------------------------------------
-constexpr int kHalf = 256;  // threads per feature inside a k_spectrum workgroup (4 wavefronts)
+constexpr int kHalf = 256;  // threads per feature when a k_spectrum workgroup evaluates both features (TPF)
 #ifndef TSFF_QUNROLL
 #define TSFF_QUNROLL 1  // unroll factor of the strip loop (points interleaved per thread)
 #endif
@@ -470,17 +470,21 @@ __device__ __forceinline__ void stage_phys(const KStatic& S, const double* __res
   __syncthreads();
 }
 
-// reductions over the 4 wavefronts of one feature half; every thread of the WORKGROUP must call them
-// (they contain workgroup barriers).  scratch: 16 doubles.
+// reductions over the NW wavefronts of one feature group; every thread of the WORKGROUP must call them
+// (they contain workgroup barriers).  scratch: 32 doubles.
+template <int NW>
 __device__ __forceinline__ double half_sum(double v, double* scratch, int half, int hw, int lane) {
   v = wave_sum(v);
   __syncthreads();
-  if (lane == 0) scratch[half * 4 + hw] = v;
+  if (lane == 0) scratch[half * NW + hw] = v;
   __syncthreads();
-  const double* r = scratch + half * 4;
-  return (r[0] + r[1]) + (r[2] + r[3]);
+  const double* r = scratch + half * NW;
+  double s = (r[0] + r[1]) + (r[2] + r[3]);
+  if (NW == 8) s += (r[4] + r[5]) + (r[6] + r[7]);
+  return s;
 }
 
+template <int NW>
 __device__ __forceinline__ void half_argmax(double& v, int& idx, double* scratch, int half, int hw, int lane) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -489,13 +493,13 @@ __device__ __forceinline__ void half_argmax(double& v, int& idx, double* scratch
     if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
   }
   __syncthreads();
-  if (lane == 0) { scratch[half * 8 + hw] = v; scratch[half * 8 + 4 + hw] = (double)idx; }
+  if (lane == 0) { scratch[half * 2 * NW + hw] = v; scratch[half * 2 * NW + NW + hw] = (double)idx; }
   __syncthreads();
-  const double* r = scratch + half * 8;
-  v = r[0]; idx = (int)r[4];
+  const double* r = scratch + half * 2 * NW;
+  v = r[0]; idx = (int)r[NW];
 #pragma unroll
-  for (int k = 1; k < 4; ++k) {
-    const double ov = r[k]; const int oi = (int)r[4 + k];
+  for (int k = 1; k < NW; ++k) {
+    const double ov = r[k]; const int oi = (int)r[NW + k];
     if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
   }
 }
@@ -518,15 +522,18 @@ __device__ __forceinline__ void loss_point(int method, double d, double t, doubl
 //   MODE 1: + masked loss sums + adjoint -> grad      (LossFunction.vg_loss)
 //   MODE 2: + per-lineout sums, theory denominator, sqdev arrays (LossFunction.array_loss)
 // ------------------------------------------------------------------------------------------
-template <int NI, int MODE, bool WM = false>
+template <int NI, int MODE, bool WM = false, int TPF = kHalf>
 __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCall K, int f0, int nfeat, int flags,
                                                            const uint8_t* __restrict__ gmask, double* __restrict__ grad) {
   // flags bit 0: add to grad instead of overwriting it (second launch of a feature-split call);
   //       bit 1: k_s cache present in LDS
   const bool accumulate = flags & 1, use_ks = flags & 2;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int half = tid >> 8, ht = tid & (kHalf - 1), lane = tid & 63, hw = (tid >> 6) & 3;
-  const int f = f0 + half;  // feature of this half (wavefront-uniform)
+  // TPF threads per feature: 256 when the workgroup holds both features, 512 for a one-feature workgroup
+  constexpr int NW = TPF / 64;          // wavefronts per feature
+  constexpr int BPT = TSFF_NBINS / TPF;  // output bins per thread
+  const int half = tid / TPF, ht = tid % TPF, lane = tid & 63, hw = ht >> 6;
+  const int f = f0 + half;  // feature of this group (wavefront-uniform)
   extern __shared__ __align__(16) unsigned char smem[];
   const Smem m = carve(smem, S, nfeat, WM, use_ks);
   Tables T;
@@ -536,15 +543,15 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   stage_phys<NI>(S, xpar, m.phys);
   const double lam_shift = S.lam_shift[f];
   const double* __restrict__ omgs = S.omgs[f];
-  const int npts = S.npts, ppp = S.ppp, G = S.G, NA = S.n_angles;
+  const int npts = S.npts, ppp = S.ppp, G = S.G, NA = S.n_angles, nstrips = S.npts / kStrip;
   const double invG = 1.0 / (double)G;
   // (pointer arithmetic on the LDS base, not a runtime-indexed pointer array: keeps ds_* addressing)
   const int H = S.halo;
   double* __restrict__ xs = m.x[0] + half * (S.npts + 2 * H) + H;
   const int Hb = S.halo_bins;
   double* __restrict__ ybs = m.yb[0] + half * (TSFF_NBINS + 2 * Hb) + Hb;
-  for (int i = ht - H; i < npts + H; i += kHalf) xs[i] = 0.0;
-  for (int i = ht - Hb; i < TSFF_NBINS + Hb; i += kHalf) ybs[i] = 0.0;
+  for (int i = ht - H; i < npts + H; i += TPF) xs[i] = 0.0;
+  for (int i = ht - Hb; i < TSFF_NBINS + Hb; i += TPF) ybs[i] = 0.0;
   __syncthreads();
 
   // ================= forward sweep over (gradient point, lambda strip, angle) =================
@@ -560,11 +567,11 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     }
     if (use_ks) {
       if (g > 0) __syncthreads();
-      for (int i = ht; i < npts; i += kHalf) ksc[i] = ks_eval(omgs[i], L.wpe2);  // angle independent (form_factor.py:218)
+      for (int i = ht; i < npts; i += TPF) ksc[i] = ks_eval(omgs[i], L.wpe2);  // angle independent (form_factor.py:218)
       __syncthreads();
     }
-    for (int c = 0; c < ppp; ++c) {
-      const int j0 = kStrip * (ht + kHalf * c);
+    for (int st = ht; st < nstrips; st += TPF) {
+      const int j0 = kStrip * st;
       // the frequency axis is read from global memory (L1/L2): the strip's first two samples once per
       // chunk, the others one iteration ahead of their use so the load latency hides behind a whole point
       const double ws_first = omgs[j0], ws_second = omgs[min(j0 + 1, npts - 1)];
@@ -589,8 +596,8 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     }
   }
   if (f == TSFF_FEATURE_ELE && S.filt)
-    for (int c = 0; c < ppp; ++c) {
-      const int j0 = kStrip * (ht + kHalf * c);
+    for (int st = ht; st < nstrips; st += TPF) {
+      const int j0 = kStrip * st;
 #pragma unroll
       for (int q = 0; q < kStrip; ++q) xs[j0 + q] *= S.filt[j0 + q];
     }
@@ -601,25 +608,25 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   // ybin[p] = sum_s hb[s] x[p ppp + toff + s]  (irf.py:72-74 / 114,124 in one pass; zero halo -> no bounds checks)
   const int nh = S.ntaps[f], toff = S.toff[f];
   const double* __restrict__ taps = m.taps[0] + (f == TSFF_FEATURE_ELE ? 0 : S.ntaps[0]);
-  double ybin[4] = {0.0, 0.0, 0.0, 0.0};
+  double ybin[BPT];
+#pragma unroll
+  for (int r = 0; r < BPT; ++r) ybin[r] = 0.0;
   {
     const double* __restrict__ x0 = xs + toff + ht * ppp;
-    const int rs = kHalf * ppp;
+    const int rs = TPF * ppp;
 #pragma unroll 4
-    for (int t = 0; t < nh; ++t) {  // one tap read feeds the thread's four bins
+    for (int t = 0; t < nh; ++t) {  // one tap read feeds all the thread's bins
       const double g = taps[t];
-      ybin[0] += g * x0[t];
-      ybin[1] += g * x0[rs + t];
-      ybin[2] += g * x0[2 * rs + t];
-      ybin[3] += g * x0[3 * rs + t];
+#pragma unroll
+      for (int r = 0; r < BPT; ++r) ybin[r] += g * x0[r * rs + t];
     }
   }
   double M = ybin[0];
   int pstar = ht;
 #pragma unroll
-  for (int r = 1; r < 4; ++r)
-    if (ybin[r] > M) { M = ybin[r]; pstar = ht + kHalf * r; }
-  half_argmax(M, pstar, m.red, half, hw, lane);
+  for (int r = 1; r < BPT; ++r)
+    if (ybin[r] > M) { M = ybin[r]; pstar = ht + TPF * r; }
+  half_argmax<NW>(M, pstar, m.red, half, hw, lane);
   const double invM = 1.0 / M;
   const double amps = K.amps[f][b];
   double p_lam, p_amp1, p_amp2, p_amp3;
@@ -628,12 +635,12 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     p_amp2 = uni(m.phys[TSFF_P_AMP2]); p_amp3 = uni(m.phys[TSFF_P_AMP3]);
   }
   const double* __restrict__ lamb = S.lam_bin[f];
-  double Tb[4];  // dLoss/dT (MODE 1)
-  double Ap[4];  // amplitude factor of bin p
+  double Tb[BPT];  // dLoss/dT (MODE 1)
+  double Ap[BPT];  // amplitude factor of bin p
   double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int pb = ht + kHalf * r;
+  for (int r = 0; r < BPT; ++r) {
+    const int pb = ht + TPF * r;
     double A;
     if (f == TSFF_FEATURE_ELE) A = amps * (lamb[pb] < p_lam ? p_amp1 : p_amp2);  // irf.py:126-130
     else A = amps * p_amp3;                                                      // irf.py:76
@@ -667,8 +674,8 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     }
   }
   if (MODE == 0) return;
-  s0 = half_sum(s0, m.red, half, hw, lane);
-  s1 = half_sum(s1, m.red, half, hw, lane);
+  s0 = half_sum<NW>(s0, m.red, half, hw, lane);
+  s1 = half_sum<NW>(s1, m.red, half, hw, lane);
   if (ht == 0) {
     if (f == TSFF_FEATURE_ELE) { K.lpart[(size_t)b * 3 + 1] = s0; K.lpart[(size_t)b * 3 + 2] = s1; }
     else K.lpart[(size_t)b * 3 + 0] = s0;
@@ -679,19 +686,19 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   // T_p = A_p ybin_p / M (+ noise), M = max_p ybin_p attained at pstar
   double sn = 0.0, a1b = 0.0, a2b = 0.0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int pb = ht + kHalf * r;
+  for (int r = 0; r < BPT; ++r) {
+    const int pb = ht + TPF * r;
     const double u = Tb[r] * ybin[r] * invM;  // dL/dA_p
     sn += u * Ap[r];
     if (f == TSFF_FEATURE_ELE) { if (lamb[pb] < p_lam) a1b += u * amps; else a2b += u * amps; }
     else a1b += u * amps;
   }
-  sn = half_sum(sn, m.red, half, hw, lane);
-  a1b = half_sum(a1b, m.red, half, hw, lane);
-  a2b = half_sum(a2b, m.red, half, hw, lane);
+  sn = half_sum<NW>(sn, m.red, half, hw, lane);
+  a1b = half_sum<NW>(a1b, m.red, half, hw, lane);
+  a2b = half_sum<NW>(a2b, m.red, half, hw, lane);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int pb = ht + kHalf * r;
+  for (int r = 0; r < BPT; ++r) {
+    const int pb = ht + TPF * r;
     double yb = Tb[r] * Ap[r] * invM;
     if (pb == pstar) yb -= sn * invM;
     ybs[pb] = yb;
@@ -699,25 +706,25 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   __syncthreads();
   // ================= adjoint of convolution + binning: xbar_i = filt_i sum_p ybar_p hb[i - p ppp - toff] =================
   if (ppp == 1) {
-    double sx[4] = {0.0, 0.0, 0.0, 0.0};
+    double sx[BPT];
+#pragma unroll
+    for (int r = 0; r < BPT; ++r) sx[r] = 0.0;
     const double* __restrict__ y0 = ybs - toff + ht;
 #pragma unroll 4
     for (int t = 0; t < nh; ++t) {
       const double g = taps[t];
-      sx[0] += g * y0[-t];
-      sx[1] += g * y0[kHalf - t];
-      sx[2] += g * y0[2 * kHalf - t];
-      sx[3] += g * y0[3 * kHalf - t];
+#pragma unroll
+      for (int r = 0; r < BPT; ++r) sx[r] += g * y0[r * TPF - t];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = ht + kHalf * r;
+    for (int r = 0; r < BPT; ++r) {
+      const int i = ht + TPF * r;
       double v = sx[r];
       if (f == TSFF_FEATURE_ELE && S.filt) v *= S.filt[i];
       xs[i] = v * invG;
     }
   } else {
-    for (int i = ht; i < npts; i += kHalf) {
+    for (int i = ht; i < npts; i += TPF) {
       const int q = i - toff;           // >= 0: toff = -dmax <= 0
       int pb = q / ppp;
       double sv = 0.0;
@@ -744,11 +751,11 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     zero_lines<NI>(LB);
     if (use_ks && G > 1) {  // (with one gradient point the cache of the forward sweep is still valid)
       __syncthreads();
-      for (int i = ht; i < npts; i += kHalf) ksc[i] = ks_eval(omgs[i], L.wpe2);
+      for (int i = ht; i < npts; i += TPF) ksc[i] = ks_eval(omgs[i], L.wpe2);
       __syncthreads();
     }
-    for (int c = 0; c < ppp; ++c) {
-      const int j0 = kStrip * (ht + kHalf * c);
+    for (int st = ht; st < nstrips; st += TPF) {
+      const int j0 = kStrip * st;
       const double ws_first = omgs[j0], ws_second = omgs[min(j0 + 1, npts - 1)];
       for (int a = 0; a < NA; ++a) {
         const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a]);
@@ -796,9 +803,13 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       }
       __syncthreads();
       if (ht == 0) {
-        const double* r = m.red + (half * 4) * NLB;
+        const double* r = m.red + (half * NW) * NLB;
 #pragma unroll
-        for (int k = 0; k < NLB; ++k) lb[k] = (r[k] + r[NLB + k]) + (r[2 * NLB + k] + r[3 * NLB + k]);
+        for (int k = 0; k < NLB; ++k) {
+          double v = (r[k] + r[NLB + k]) + (r[2 * NLB + k] + r[3 * NLB + k]);
+          if (NW == 8) v += (r[4 * NLB + k] + r[5 * NLB + k]) + (r[6 * NLB + k] + r[7 * NLB + k]);
+          lb[k] = v;
+        }
         LB.wpe2 = lb[0]; LB.wL = lb[1]; LB.kL = lb[2]; LB.ivTe = lb[3]; LB.a_e = lb[4]; LB.pref = lb[5]; LB.Ud = lb[6]; LB.Vd = lb[7];
 #pragma unroll
         for (int s = 0; s < NI; ++s) { LB.ixi[s] = lb[8 + 3 * s]; LB.a_i[s] = lb[9 + 3 * s]; LB.cs[s] = lb[10 + 3 * s]; }
