@@ -123,24 +123,6 @@ struct Tables {
   int nvx;
 };
 
-// jnp.interp(xi, xi2, Zp, left=xi**-2 / 0, right=xi**-2 / 0)  (form_factor.py:247-248)
-__device__ __forceinline__ void zprime_lookup(const double2* zp, double xi, double& zr, double& zi,
-                                              double& dzr, double& dzi) {
-  const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
-  double u = (xi - kXi2_0) * kXi2_ih;
-  int i = (int)u;
-  i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
-  const double t = (xi - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
-  const double2 a = zp[i], b = zp[i + 1];
-  const double dr = b.x - a.x, di = b.y - a.y;
-  if (xi < kXi2_0 || xi > xlast) {
-    const double i2 = frcp(xi * xi);
-    zr = i2; zi = 0.0; dzr = -2.0 * i2 * i2 * xi; dzi = 0.0;
-  } else {
-    zr = a.x + t * dr; zi = a.y + t * di; dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
-  }
-}
-
 // jnp.interp(xie, xi2, W): clamps to the end values outside the table (form_factor.py:270)
 __device__ __forceinline__ void w_lookup(const double* W, double xe, double& w, double& dw) {
   const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
@@ -383,9 +365,10 @@ __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const
 }
 
 // ion terms of one species at normalised phase velocity xi (form_factor.py:243-249, 277-280):
-// Z'(xi) with its slope and gs = exp(-xi^2)/sqrt(2 pi).  Two wavefront-uniform fast paths: the EPW
-// window is almost entirely beyond the Z' table and far enough for exp(-xi^2) to vanish (|xi| > 28:
-// exp(-784) = 0 in float64); the IAW window is almost entirely inside the table.
+// Z'(xi) = jnp.interp(xi, xi2, Zp, left=xi**-2 / 0, right=xi**-2 / 0) with its slope, and
+// gs = exp(-xi^2)/sqrt(2 pi).  (TSFF_FASTPATH: optional wavefront-uniform shortcuts -- the EPW window is
+// almost entirely beyond the Z' table and far enough for exp(-xi^2) to vanish, the IAW window almost
+// entirely inside the table; measured slower than the branch-free form, off by default.)
 __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& zr, double& zi, double& dzr,
                                           double& dzi, double& gs) {
 #if TSFF_FASTPATH

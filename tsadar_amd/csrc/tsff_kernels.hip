@@ -361,9 +361,9 @@ struct Smem {
   double2* zp;    // [1640]
   double2* ht;    // [nvx]
   double* W;      // [1640]
-  double* x[2];   // [npts]   model spectrum of each feature, later its adjoint
-  double* yb[2];  // [1024]   adjoint of the binned spectrum (MODE 1)
-  double* taps[2];
+  double* x;      // [nfeat][halo + npts + halo]   model spectrum of each feature, later its adjoint
+  double* yb;     // [nfeat][halo_bins + 1024 + halo_bins]   adjoint of the binned spectrum (MODE 1)
+  double* taps;   // [ntaps[0] + ntaps[1]] bin-averaged IRF taps of both features
   double2* hc;    // [2*(nvx-1)] Hermite coefficients per interval
   double2* hcm;   // the same for d ln fe / dm
   double* Wm;     // [1640] dW/dm
@@ -394,17 +394,14 @@ __device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int
   double* p = m.W + kNXi2;
   // one buffer per feature holds the model spectrum x and later its adjoint, another the adjoint of the binned
   // spectrum; zero halos on both sides so the convolutions need no bounds checks
-  m.x[0] = p; p += (size_t)nfeat * (S.npts + 2 * S.halo);
-  m.x[1] = nullptr;
-  m.yb[0] = p; p += (size_t)nfeat * (TSFF_NBINS + 2 * S.halo_bins);
-  m.yb[1] = nullptr;
+  m.x = p; p += (size_t)nfeat * (S.npts + 2 * S.halo);
+  m.yb = p; p += (size_t)nfeat * (TSFF_NBINS + 2 * S.halo_bins);
   m.hc = reinterpret_cast<double2*>(p); p += 4 * (size_t)S.nvx;
   m.hcm = nullptr; m.Wm = nullptr;
   if (with_m) { m.hcm = reinterpret_cast<double2*>(p); p += 4 * (size_t)S.nvx; m.Wm = p; p += kNXi2; }
   m.ksc = nullptr;
   if (with_ks) { m.ksc = p; p += (size_t)nfeat * (S.npts + 2); }
-  m.taps[0] = p; p += S.ntaps[0];
-  m.taps[1] = p; p += S.ntaps[1];
+  m.taps = p; p += S.ntaps[0] + S.ntaps[1];
   m.phys = p; p += kNP_MAX + 2;
   m.cosa = p; p += S.n_angles;
   m.wsa = p; p += S.n_angles;
@@ -436,8 +433,8 @@ __device__ __forceinline__ void load_tables(const Smem& m, const KStatic& S, con
     for (int i = tid; i < kNXi2; i += nthr) m.Wm[i] = K.Wm[(size_t)slot * kNXi2 + i];
   }
   if (with_taps) {
-    for (int i = tid; i < S.ntaps[0]; i += nthr) m.taps[0][i] = S.taps[0][i];
-    for (int i = tid; i < S.ntaps[1]; i += nthr) m.taps[1][i] = S.taps[1][i];
+    for (int i = tid; i < S.ntaps[0]; i += nthr) m.taps[i] = S.taps[0][i];
+    for (int i = tid; i < S.ntaps[1]; i += nthr) m.taps[S.ntaps[0] + i] = S.taps[1][i];
   }
   for (int i = tid; i < S.n_angles; i += nthr) { m.cosa[i] = S.cos_sa[i]; m.wsa[i] = S.w_sa[i]; }
   T.zp = m.zp; T.W = m.W; T.ht = m.ht; T.hc = m.hc; T.hcm = m.hcm; T.Wm = m.Wm; T.nvx = S.nvx;
@@ -547,9 +544,9 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   const double invG = 1.0 / (double)G;
   // (pointer arithmetic on the LDS base, not a runtime-indexed pointer array: keeps ds_* addressing)
   const int H = S.halo;
-  double* __restrict__ xs = m.x[0] + half * (S.npts + 2 * H) + H;
+  double* __restrict__ xs = m.x + half * (S.npts + 2 * H) + H;
   const int Hb = S.halo_bins;
-  double* __restrict__ ybs = m.yb[0] + half * (TSFF_NBINS + 2 * Hb) + Hb;
+  double* __restrict__ ybs = m.yb + half * (TSFF_NBINS + 2 * Hb) + Hb;
   for (int i = ht - H; i < npts + H; i += TPF) xs[i] = 0.0;
   for (int i = ht - Hb; i < TSFF_NBINS + Hb; i += TPF) ybs[i] = 0.0;
   __syncthreads();
@@ -607,7 +604,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   // the host folds the bin average into the taps: hb[s] = (1/ppp) sum_jj g[jj - s + nt - 1], so that
   // ybin[p] = sum_s hb[s] x[p ppp + toff + s]  (irf.py:72-74 / 114,124 in one pass; zero halo -> no bounds checks)
   const int nh = S.ntaps[f], toff = S.toff[f];
-  const double* __restrict__ taps = m.taps[0] + (f == TSFF_FEATURE_ELE ? 0 : S.ntaps[0]);
+  const double* __restrict__ taps = m.taps + (f == TSFF_FEATURE_ELE ? 0 : S.ntaps[0]);
   double ybin[BPT];
 #pragma unroll
   for (int r = 0; r < BPT; ++r) ybin[r] = 0.0;
