@@ -62,7 +62,7 @@ enum {
 #define TSFF_ION_FRACT 3
 #define TSFF_NP(n_ion) (TSFF_P_ION0 + 4 * (n_ion))
 #define TSFF_MAX_ION 4
-#define TSFF_MAX_ANGLES 64
+#define TSFF_MAX_ANGLES 1024
 #define TSFF_NBINS 1024 /* irf.py:74,124: reshape(1024, -1) */
 #define TSFF_NXI2 1640  /* form_factor.py:138 */
 #define TSFF_NXI1 1024  /* form_factor.py:137 */
@@ -163,6 +163,15 @@ int tsff_chi_table(tsff_handle *h, const double *fe, int32_t n, double *W);
  * (no activation); fe is [B][nvx] (PER_LINEOUT), ignored otherwise. */
 int tsff_form_factor(tsff_handle *h, int32_t feature, const double *phys, const double *fe,
                      int32_t B, double *P);
+
+/* FormFactor.calc_in_2D (core/physics/form_factor.py:449-587, with rotate :300-324 and calc_chi_vals :349-388)
+ * for a 2-D electron distribution fe2d[nv][nv] on the grid linspace(-6 + dv/2, 6 - dv/2, nv) (first index = v_x;
+ * one table shared by all lineouts when shared_fe != 0, else [B][nv][nv]): P[B][G][npts][n_angles].  `phys` holds
+ * PHYSICAL parameters [B][NP]; ud_angle / va_angle are the drift and flow directions in degrees
+ * (parameters.general.ud.angle / Va.angle).  Forward only.  Parity with the reference is unpinned for this entry:
+ * its golden vectors are not part of the reference source tree. */
+int tsff_form_factor_2d(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
+                        int32_t shared_fe, double ud_angle_deg, double va_angle_deg, int32_t B, double *P);
 
 /* ThomsonScatteringDiagnostic.__call__: ThryE/ThryI [B][1024].  noise_* may be NULL (= 0).
  * params: normalised leaves [B][NP]; fe: [B][nvx] when fe_mode == PER_LINEOUT else NULL. */

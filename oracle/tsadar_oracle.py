@@ -609,3 +609,135 @@ def fd_gradient(cfg, sa, normed, batch, i_norm, e_norm, names, h=1e-6, activate=
             g[b] = (lu - ld) / (2 * h)
         out[nm] = g
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-D distribution functions: FormFactor.calc_in_2D (form_factor.py:300-324, 349-388, 449-587)
+#
+# PARITY UNPINNED against the reference: its goldens for this path (tests/test_forward/ThryE-arts2v.npy)
+# are not in the source tree, and interpax.interp2d's "cubic" is restated from its published definition
+# (bicubic Hermite patch with derivative estimates fx, fy, fxy = mean of adjacent secants, one-sided at
+# the edges; extrap=True evaluates the boundary patch outside the grid).
+# ---------------------------------------------------------------------------------------------
+def approx_df_axis(x, f, axis):
+    """interpax ``approx_df(x, f, "cubic", axis)``: mean of the two adjacent secants, one-sided at the ends."""
+    f = np.moveaxis(f, axis, 0)
+    d = np.diff(f, axis=0) / np.diff(x).reshape((-1,) + (1,) * (f.ndim - 1))
+    out = np.concatenate([d[:1], 0.5 * (d[:-1] + d[1:]), d[-1:]], axis=0)
+    return np.moveaxis(out, 0, axis)
+
+
+def interp2d_cubic_extrap(xq, yq, x, y, f):
+    """``interpax.interp2d(xq, yq, x, y, f, method="cubic", extrap=True)`` (call site form_factor.py:324)."""
+    fx = approx_df_axis(x, f, 0)
+    fy = approx_df_axis(y, f, 1)
+    fxy = approx_df_axis(y, fx, 1)
+    i = np.clip(np.searchsorted(x, xq, side="right"), 1, len(x) - 1)
+    j = np.clip(np.searchsorted(y, yq, side="right"), 1, len(y) - 1)
+    dx = x[i] - x[i - 1]
+    dy = y[j] - y[j - 1]
+    tx = (xq - x[i - 1]) / dx
+    ty = (yq - y[j - 1]) / dy
+
+    def basis(t):
+        t2, t3 = t * t, t * t * t
+        return (2 * t3 - 3 * t2 + 1, -2 * t3 + 3 * t2), (t3 - 2 * t2 + t, t3 - t2)
+
+    (hx0, hx1), (gx0, gx1) = basis(tx)
+    (hy0, hy1), (gy0, gy1) = basis(ty)
+    out = 0.0
+    for a, (hxa, gxa) in enumerate(((hx0, gx0), (hx1, gx1))):
+        for b, (hyb, gyb) in enumerate(((hy0, gy0), (hy1, gy1))):
+            ii, jj = i - 1 + a, j - 1 + b
+            out = out + f[ii, jj] * hxa * hyb + fx[ii, jj] * dx * gxa * hyb + fy[ii, jj] * dy * hxa * gyb \
+                + fxy[ii, jj] * dx * dy * gxa * gyb
+    return out
+
+
+def rotate_df(vx, df, angle_deg):
+    """``FormFactor.rotate`` (form_factor.py:300-324): out[ix, iy] = DF interpolated at the point
+    (vx[ix], vx[iy]) rotated by +angle (meshgrid 'xy' flattened in C order, result reshaped in F order)."""
+    rad = np.deg2rad(-angle_deg)
+    c, s = np.cos(rad), np.sin(rad)
+    X, Y = np.meshgrid(vx, vx, indexing="ij")  # X[ix, iy] = vx[ix], Y[ix, iy] = vx[iy]
+    xq = c * X + s * Y
+    yq = -s * X + c * Y
+    return interp2d_cubic_extrap(xq.ravel(), yq.ravel(), vx, vx, df).reshape(vx.size, vx.size)
+
+
+def calc_chi_vals_2d(vx, DF, beta, xie_mag, klde_mag):
+    """``FormFactor.calc_chi_vals`` (form_factor.py:349-388) for one (lambda, theta) point."""
+    dvx = vx[1] - vx[0]
+    fe_2D_k = rotate_df(vx, DF, beta * 180 / np.pi)
+    fe_1D_k = np.sum(fe_2D_k, axis=0) * dvx
+    df = gradient_uniform(fe_1D_k, dvx)
+    fe_vphi = np.interp(xie_mag, vx, fe_1D_k)
+    dfe = np.interp(xie_mag, vx, df)
+    chiEI = np.pi / klde_mag**2 * dfe
+    chiERrat = -1.0 / klde_mag**2 * ratintn(df, vx - xie_mag, vx)
+    return fe_vphi, chiEI, chiERrat
+
+
+def form_factor_2d(lam_range, npts, lam_shift, sa_deg, num_grad_points, p, vx, fe2d, ud_angle, va_angle, lam_index=None):
+    """``FormFactor.calc_in_2D`` (form_factor.py:449-587), one lineout.  Returns (P[G, npts, ntheta], lam_cm).
+    ``lam_index`` restricts the evaluation to a subset of the wavelength samples (the 2-D path has no coupling
+    along lambda), which keeps this O(npts * ntheta * nv^2) restatement affordable in tests."""
+    _, xi2 = xi_grids()
+    zr_tab, zi_tab = zprime_tables()
+    G = num_grad_points
+    lam_axis = np.linspace(lam_range[0], lam_range[1], npts)
+    if lam_index is not None:
+        lam_axis = lam_axis[np.asarray(lam_index)]
+    omgL_num = 2 * np.pi * 1e7 * C
+    omgs = (2e7 * np.pi * C / lam_axis)[None, :, None]
+    ne = 1.0e20 * p["ne"] * np.linspace(1 - p["ne_gradient"] / 200, 1 + p["ne_gradient"] / 200, G)
+    Te = p["Te"] * np.linspace(1 - p["Te_gradient"] / 200, 1 + p["Te_gradient"] / 200, G)
+    lam = p["lam"] + lam_shift
+    A = np.asarray(p["A"], dtype=np.float64)
+    Z = np.asarray(p["Z"], dtype=np.float64).reshape(1, 1, 1, -1)
+    Ti = np.asarray(p["Ti"], dtype=np.float64)
+    fract = np.asarray(p["fract"], dtype=np.float64).reshape(1, 1, 1, -1)
+    Va0, ud0 = p["Va"] * 1e6, p["ud"] * 1e6
+    Mi = (A * MP).reshape(1, 1, 1, -1)
+    sarad = (np.asarray(sa_deg, dtype=np.float64) * np.pi / 180).reshape(1, 1, -1)
+    Va = (Va0 * np.cos(va_angle * np.pi / 180), Va0 * np.sin(va_angle * np.pi / 180))
+    ud = (ud0 * np.cos(ud_angle * np.pi / 180), ud0 * np.sin(ud_angle * np.pi / 180))
+    omgL = omgL_num / lam
+    omgpe = C0 * np.sqrt(ne[:, None, None])
+    omg = omgs - omgL
+    kLx = np.sqrt(omgL**2 - omgpe**2) / C
+    ks_mag = np.sqrt(omgs**2 - omgpe**2) / C
+    kx, ky = np.cos(sarad) * ks_mag - kLx, np.sin(sarad) * ks_mag - 0.0
+    k_mag = np.sqrt(kx * kx + ky * ky)
+    omgdop = omg - (kx * Va[0] + ky * Va[1])
+    vTe = np.sqrt(Te[:, None, None] / ME)
+    klde_mag = (vTe / omgpe) * k_mag
+    Zbar = np.sum(Z * fract)
+    ni = fract * ne[:, None, None, None] / Zbar
+    omgpi = C0 * Z * np.sqrt(ni * ME / Mi)
+    vTi = np.sqrt(Ti.reshape(1, 1, 1, -1) / Mi)
+    kldi = (vTi / omgpi) * k_mag[..., None]
+    xii = (1.0 / (np.sqrt(2.0) * vTi)) * (omgdop / k_mag)[..., None]
+    ZpiR = interp_linear(xii, xi2, zr_tab, left=xii**-2, right=xii**-2)
+    ZpiI = interp_linear(xii, xi2, zi_tab, left=0.0, right=0.0)
+    chiI = np.sum(-0.5 / kldi**2 * (ZpiR + 1j * ZpiI), axis=3)
+    a = omgdop / k_mag**2
+    xie = ((a * kx - ud[0]) / vTe, (a * ky - ud[1]) / vTe)
+    xie_mag = np.sqrt(xie[0] ** 2 + xie[1] ** 2)
+    beta = np.arctan(xie[1] / xie[0]) + np.pi * (-np.heaviside(xie[0], 1) + 1)
+    shp = beta.shape
+    fe_vphi = np.empty(shp)
+    chiEI = np.empty(shp)
+    chiER = np.empty(shp)
+    for idx in np.ndindex(*shp):
+        fe_vphi[idx], chiEI[idx], chiER[idx] = calc_chi_vals_2d(vx, fe2d, beta[idx], xie_mag[idx], klde_mag[idx])
+    chiE = chiER + 1j * chiEI
+    eps = 1.0 + chiE + chiI
+    ion_fact = fract * Z**2 / Zbar / vTi
+    ion_comp = ion_fact * (np.abs(chiE[..., None]) ** 2 * np.exp(-(xii**2)) / np.sqrt(2 * np.pi))
+    ele_comp = np.abs(1.0 + chiI) ** 2 * fe_vphi / vTe
+    S_ion = np.sum(1.0 / k_mag[..., None] * ion_comp / np.abs(eps[..., None]) ** 2, axis=3)
+    S_ele = 1.0 / k_mag * ele_comp / np.abs(eps) ** 2
+    PsOmg = (S_ion + S_ele) * (1 + 2 * omgdop / omgL) * RE**2 * ne[:, None, None]
+    lams = 2 * np.pi * C / omgs
+    return PsOmg * 2 * np.pi * C / lams**2, lams[0, :, 0]

@@ -556,3 +556,39 @@ def test_hessian_for_sigmas(torch_mod):
         sg = np.sign(np.diag(np.linalg.inv(Hg))) * np.sqrt(np.abs(np.diag(np.linalg.inv(Hg))))
         so = np.sign(np.diag(np.linalg.inv(Ho))) * np.sqrt(np.abs(np.diag(np.linalg.inv(Ho))))
         np.testing.assert_allclose(sg, so, rtol=5e-3)
+
+
+def _fe2d(nv, kind):
+    vx = orc.velocity_grid(nv)
+    X, Y = np.meshgrid(vx, vx, indexing="ij")
+    if kind == "maxwellian":
+        f = np.exp(-(X**2 + Y**2) / 2)
+    else:  # anisotropic super-Gaussian with a drifting bump: no symmetry left for a transposed index to hide behind
+        f = np.exp(-((X / 1.3) ** 2 + (Y / 0.8) ** 2) ** 1.4 / 2) + 0.05 * np.exp(-((X - 2.0) ** 2 + (Y + 1.0) ** 2))
+    return vx, f / (f.sum() * (vx[1] - vx[0]) ** 2)
+
+
+@pytest.mark.parametrize("kind,nv", [("maxwellian", 48), ("anisotropic", 48), ("anisotropic", 132)])
+def test_form_factor_2d_matches_oracle(torch_mod, kind, nv):
+    """a16: FormFactor.calc_in_2D (rotate + project + ratintn per (lambda, theta) point) vs the oracle's
+    restatement on a subset of wavelengths; non-zero drift and flow at oblique angles.  (Parity with the reference
+    itself is unpinned for this path: its goldens are not in the reference tree.)"""
+    cfg = decks.deck_fit()
+    B = 2  # nv = 48: table resident in LDS; nv = 132 (> 128): table read through L1/L2
+    sa = dict(sa=np.array([35.0, 60.0, 110.0]), weights=np.ones((B, 3)) / 3)
+    eng = _engine(cfg, sa)
+    normed = util.random_lineouts(cfg, B, seed=61, ranges=dict(ud=(-1.5, 1.5)))
+    phys = orc.physical_params(cfg["parameters"], normed, True)
+    phys["ud"] = np.array([0.8, -1.1])
+    X = util.normed_to_matrix(phys, 1)
+    vx, fe2 = _fe2d(nv, kind)
+    ud_ang, va_ang = 25.0, -40.0
+    idx = np.array([0, 1, 100, 333, 511, 512, 700, 1023]) if nv < 100 else np.array([0, 400, 1023])
+    for feature, rng in ((0, cfg["other"]["lamrangE"]), (1, cfg["other"]["lamrangI"])):
+        P = eng.form_factor_2d(feature, X, fe2, ud_ang, va_ang).cpu().numpy()
+        assert P.shape == (B, 1, 1024, 3) and np.all(np.isfinite(P))
+        for b in range(B):
+            p = orc.lineout_params(phys, b, 1)
+            Po, _ = orc.form_factor_2d(rng, 1024, 0.0, sa["sa"], 1, p, vx, fe2, ud_ang, va_ang, lam_index=idx)
+            err = np.max(np.abs(P[b][:, idx, :] - Po) / np.abs(Po))
+            assert err < 1e-7, (feature, b, err)

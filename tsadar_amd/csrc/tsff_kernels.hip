@@ -23,6 +23,7 @@ struct KStatic {
   const double* lam_bin[2];  // [1024] binned wavelength axis in nm (irf.py:75,125)
   const double* filt;        // [npts] EPW multiplier (iawfilter) or nullptr
   const double* cos_sa;      // [n_angles]
+  const double* sa_rad;      // [n_angles] scattering angles in radians (2-D path)
   const double* w_sa;        // [n_angles]
   const double2* zp;         // [1640]
   const double* xi1;         // [1024]
@@ -917,6 +918,197 @@ __global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, in
           b0 = b1;
         }
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_form_factor_2d: FormFactor.calc_in_2D (form_factor.py:449-587) for a 2-D distribution function
+// fe2d[nv][nv] (first index = v_x): one workgroup per (lineout, gradient point, wavelength, angle).
+//   1. point scalars: vector k = k_s - k_L, omega_d, xi_i, chi_i, vector xi_e -> (|xi_e|, beta)   (:515-558)
+//   2. rotate(fe2d, beta) + column sum (:300-324, 371): thread iy evaluates the bicubic interpolant along the
+//      rotated line {R_beta (vx[ix], vx[iy])}, ix = 0..nv-1.  interpax's "cubic" 2-D interpolant (bicubic Hermite
+//      patch, derivative estimates = mean of adjacent secants, one-sided at the edges, extrap=True) is the tensor
+//      product of the 1-D Hermite interpolants, i.e. a 4 x 4 stencil with separable weights (Catmull-Rom in the
+//      interior, modified in the first/last cell).
+//   3. gradient of the projection, the two linear interpolations at |xi_e| and the rationally-centred integral
+//      over the nv-2 intervals (:372-387), spectrum assembly (:560-585).
+// ------------------------------------------------------------------------------------------
+// separable Hermite weights of the four nodes c-1..c+2 for cell c (0 <= c <= n-2) at local coordinate t
+__device__ __forceinline__ void hermite_weights(int c, int n, double t, double w[4]) {
+  const double t2 = t * t, t3 = t2 * t;
+  const double h00 = 2.0 * t3 - 3.0 * t2 + 1.0, h01 = -2.0 * t3 + 3.0 * t2, h10 = t3 - 2.0 * t2 + t, h11 = t3 - t2;
+  // slope at node c: (f[c+1]-f[c-1])/2 inside, f[c+1]-f[c] at the left edge (units of the grid step)
+  w[0] = 0.0; w[1] = h00; w[2] = h01; w[3] = 0.0;
+  if (c == 0) { w[1] -= h10; w[2] += h10; }
+  else { w[0] -= 0.5 * h10; w[2] += 0.5 * h10; }
+  // slope at node c+1: (f[c+2]-f[c])/2 inside, f[c+1]-f[c] at the right edge
+  if (c == n - 2) { w[1] -= h11; w[2] += h11; }
+  else { w[1] -= 0.5 * h11; w[3] += 0.5 * h11; }
+}
+
+// LDS: true -> the nv x nv table is staged once per (persistent) workgroup in LDS (nv <= 128: 128 KB), the
+// workgroup then loops over points; false -> the table is read through L1/L2 (any nv).
+template <int NI, bool LDS>
+__global__ __launch_bounds__(kThreads) void k_form_factor_2d(KStatic S, const double* __restrict__ phys,
+                                                             const double* __restrict__ fe2d, int nv, int shared_fe,
+                                                             double ud_ang, double va_ang, int f, long npoint,
+                                                             double* __restrict__ P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* f1 = reinterpret_cast<double*>(smem);   // [nv] projected distribution
+  double* d1 = f1 + nv;                           // [nv] its gradient
+  double* part = d1 + nv;                         // [4][nv] partial column sums
+  double* red = part + 4 * nv;                    // [8]
+  double* Fl = red + 8;                           // [nv][nv] (LDS variant)
+  const int tid = threadIdx.x;
+  const int NA = S.n_angles, G = S.G, npts = S.npts;
+  // thread -> (column iy, part of the ix range): nparts = 256 / nvp with nvp = nv rounded up to 64, 128 or 256
+  const int nvp = nv <= 64 ? 64 : (nv <= 128 ? 128 : 256);
+  const int nparts = nv <= 256 ? kThreads / nvp : 1;
+  const double dv = 12.0 / nv, v0 = -6.0 + 0.5 * dv, idv = 1.0 / dv;  // base.py:333-335
+  int b_loaded = -1;
+  for (long pid = blockIdx.x; pid < npoint; pid += gridDim.x) {
+    const int a = (int)(pid % NA), j = (int)((pid / NA) % npts), g = (int)((pid / ((long)NA * npts)) % G);
+    const int b = (int)(pid / ((long)NA * npts * G));
+    const double* __restrict__ Fg = fe2d + (shared_fe ? 0 : (size_t)b * nv * nv);
+    if (LDS && (b_loaded < 0 || (!shared_fe && b != b_loaded))) {
+      __syncthreads();
+      for (int i = tid; i < nv * nv; i += kThreads) Fl[i] = Fg[i];
+      b_loaded = b;
+    }
+    const double* __restrict__ F = LDS ? Fl : Fg;
+    Phys<NI> p;
+    load_phys<NI>(phys + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, false, p);
+    LineS<NI> L;
+    make_lines<NI>(p, S.lam_shift[f], g, G, L);
+    // ---- point scalars ----
+    const double ws = S.omgs[f][j], th = S.sa_rad[a];
+    const double ks = ks_eval(ws, L.wpe2);
+    const double kx = cos(th) * ks - L.kL, ky = sin(th) * ks;
+    const double k2 = kx * kx + ky * ky, k = sqrt(k2);
+    const double Vx = L.Vd * cos(va_ang), Vy = L.Vd * sin(va_ang);
+    const double Ux = L.Ud * cos(ud_ang), Uy = L.Ud * sin(ud_ang);
+    const double wd = (ws - L.wL) - (kx * Vx + ky * Vy);
+    const double aa = wd / k2;
+    const double xex = (aa * kx - Ux) * L.ivTe, xey = (aa * ky - Uy) * L.ivTe;
+    const double xmag = sqrt(xex * xex + xey * xey);
+    const double beta = atan(xey / xex) + (xex >= 0.0 ? 0.0 : kPi);   // heaviside(x, 1) = 1 at x == 0
+    const double cb = cos(beta), sb = sin(beta);
+    __syncthreads();
+    // ---- rotate + project ----
+    if (nv <= 256) {
+      const int iy = tid % nvp, pt = tid / nvp;
+      if (iy < nv) {
+        const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
+        const double y = v0 + iy * dv;
+        double acc = 0.0;
+        for (int ix = ix0; ix < ix1; ++ix) {
+          const double x = v0 + ix * dv;
+          const double xq = x * cb - y * sb, yq = x * sb + y * cb;
+          int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
+          cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
+          cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
+          double wx[4], wy[4];
+          hermite_weights(cx, nv, (xq - (v0 + cx * dv)) * idv, wx);
+          hermite_weights(cy, nv, (yq - (v0 + cy * dv)) * idv, wy);
+          double v = 0.0;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int rx = min(max(cx - 1 + m, 0), nv - 1);   // (clamped rows carry zero weight)
+            const double* __restrict__ row = F + (size_t)rx * nv;
+            double r = 0.0;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) r += wy[n] * row[min(max(cy - 1 + n, 0), nv - 1)];
+            v += wx[m] * r;
+          }
+          acc += v;
+        }
+        part[pt * nv + iy] = acc;
+      }
+      __syncthreads();
+      for (int i = tid; i < nv; i += kThreads) {
+        double sacc = 0.0;
+        for (int q = 0; q < nparts; ++q) sacc += part[q * nv + i];
+        f1[i] = sacc * dv;
+      }
+    } else {
+      for (int iy = tid; iy < nv; iy += kThreads) {
+        const double y = v0 + iy * dv;
+        double acc = 0.0;
+        for (int ix = 0; ix < nv; ++ix) {
+          const double x = v0 + ix * dv;
+          const double xq = x * cb - y * sb, yq = x * sb + y * cb;
+          int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
+          cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
+          cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
+          double wx[4], wy[4];
+          hermite_weights(cx, nv, (xq - (v0 + cx * dv)) * idv, wx);
+          hermite_weights(cy, nv, (yq - (v0 + cy * dv)) * idv, wy);
+          double v = 0.0;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int rx = min(max(cx - 1 + m, 0), nv - 1);
+            const double* __restrict__ row = F + (size_t)rx * nv;
+            double r = 0.0;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) r += wy[n] * row[min(max(cy - 1 + n, 0), nv - 1)];
+            v += wx[m] * r;
+          }
+          acc += v;
+        }
+        f1[iy] = acc * dv;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nv; i += kThreads) {
+      double gd;
+      if (i == 0) gd = (f1[1] - f1[0]) * idv;
+      else if (i == nv - 1) gd = (f1[nv - 1] - f1[nv - 2]) * idv;
+      else gd = (f1[i + 1] - f1[i - 1]) * (0.5 * idv);
+      d1[i] = gd;
+    }
+    __syncthreads();
+    // ---- ratintn(df, vx - |xi_e|, vx): nv - 2 intervals ----
+    double psum = 0.0;
+    for (int i = tid; i < nv - 2; i += kThreads) {
+      const double f0 = d1[i], f1v = d1[i + 1];
+      const double g0 = (v0 + i * dv) - xmag, g1 = (v0 + (i + 1) * dv) - xmag;
+      const double fdif = f1v - f0, gdif = g1 - g0, fav = 0.5 * (f1v + f0), gav = 0.5 * (g1 + g0);
+      const double tmp = fav * gdif - gav * fdif;
+      double r;
+      if (fabs(gdif) < 1.0e-4 * fabs(gav)) r = fav / gav + tmp * gdif / (12.0 * gav * gav * gav);
+      else r = fdif / gdif + tmp * log(fabs((gav + 0.5 * gdif) / (gav - 0.5 * gdif))) / (gdif * gdif);
+      psum += r * dv;
+    }
+    const double R = block_sum(psum, red);
+    if (tid == 0) {
+      // jnp.interp(|xi_e|, vx, .): clamps to the end values
+      double u = (xmag - v0) * idv;
+      int i = (int)u;
+      i = i < 0 ? 0 : (i > nv - 2 ? nv - 2 : i);
+      double t = (xmag - (v0 + i * dv)) * idv;
+      t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+      const double fe_vphi = f1[i] + t * (f1[i + 1] - f1[i]);
+      const double dfe = d1[i] + t * (d1[i + 1] - d1[i]);
+      const double ike2 = L.a_e / k2;
+      const double cer = -ike2 * R, cei = kPi * ike2 * dfe;
+      double cre = 0.0, cim = 0.0, gsum = 0.0;
+      const double vph = wd / k;
+#pragma unroll
+      for (int s = 0; s < NI; ++s) {
+        const double xi = vph * L.ixi[s];
+        double zr, zi, dzr, dzi, gs;
+        ion_terms(S.zp, xi, zr, zi, dzr, dzi, gs);   // (one thread per point: the Z' table is read from global memory)
+        const double iki2 = L.a_i[s] / k2;
+        cre -= 0.5 * iki2 * zr;
+        cim -= 0.5 * iki2 * zi;
+        gsum += L.cs[s] * gs;
+      }
+      const double er = 1.0 + cer + cre, ei = cei + cim;
+      const double eps2 = er * er + ei * ei, ce2 = cer * cer + cei * cei;
+      const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
+      const double Sv = (gsum * ce2 + ci2 * fe_vphi * L.ivTe) / (k * eps2);
+      P[pid] = Sv * (1.0 + 2.0 * wd / L.wL) * L.pref * ws * ws;
     }
   }
 }

@@ -303,6 +303,24 @@ class Engine:
         L.check(self.lib, self.h, self.lib.tsff_form_factor(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), B, self._ptr(P)))
         return P
 
+    def form_factor_2d(self, feature, phys, fe2d, ud_angle=0.0, va_angle=0.0):
+        """FormFactor.calc_in_2D: phys [B, NP] PHYSICAL parameters, fe2d [nv, nv] (shared) or [B, nv, nv]
+        -> P [B, G, npts, n_angles]."""
+        torch = self.torch
+        phys_d = self.dev(phys).reshape(-1, self.NP)
+        B = phys_d.shape[0]
+        fe_d = self.dev(fe2d)
+        shared = fe_d.dim() == 2
+        nv = int(fe_d.shape[-1])
+        assert fe_d.shape[-2] == nv and (shared or fe_d.shape[0] == B)
+        G, NA = int(self._cfg_struct.num_grad_points), int(self._cfg_struct.n_angles)
+        P = torch.empty((B, G, self.npts, NA), dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        rc = self.lib.tsff_form_factor_2d(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, int(shared),
+                                          float(ud_angle), float(va_angle), B, self._ptr(P))
+        L.check(self.lib, self.h, rc)
+        return P
+
     def forward(self, params, e_amps, i_amps, noise_e=None, noise_i=None, fe=None):
         torch = self.torch
         X = self.dev(params).reshape(-1, self.NP)
