@@ -173,6 +173,26 @@ int tsff_form_factor(tsff_handle *h, int32_t feature, const double *phys, const 
 int tsff_form_factor_2d(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
                         int32_t shared_fe, double ud_angle_deg, double va_angle_deg, int32_t B, double *P);
 
+/* Angular (ARTS) instrument chain for one image P[G][npts][n_angles] (device; from tsff_form_factor_2d or, for a 1-D
+ * distribution function, tsff_form_factor): FitModel.electron_spectrum "angular_full" branch
+ * (core/physics/generate_spectra.py:193-216: weight-matrix product, iawfilter), add_ATS_IRF (core/physics/irf.py:5-47,
+ * norm == 0), reduce_ATS_to_resunit (core/thomson_diagnostic.py:78-107).  Output ThryE (device)
+ * [row_end - row_start][npts / lam_step].  Every pointer of tsff_ats_config is a HOST pointer, copied by tsff_ats_setup.
+ * Convolution taps are in the flipped "same" form y[i] = sum_s taps[s] x[i + tap_off + s] (engine.binned_taps with ppp = 1). */
+typedef struct tsff_ats_config {
+  int32_t n_px;           /* rows of the weight matrix = angular pixels (1024) */
+  const double *weights;  /* [n_px][n_angles] */
+  int32_t n_taps_ang, tap_off_ang;
+  const double *taps_ang; /* Gaussian over sas["angAxis"], ang_FWHM_ele / 2.3548 */
+  int32_t n_taps_lam, tap_off_lam;
+  const double *taps_lam; /* Gaussian over the wavelength axis, spect_FWHM_ele / 2.3548 */
+  int32_t lam_step, ang_step; /* thomson_diagnostic.py:93-94 */
+  int32_t row_start, row_end; /* data.lineouts.start / end (rows of the reduced image) */
+  const double *lam_axis;     /* [npts] wavelength axis in nm */
+} tsff_ats_config;
+int tsff_ats_setup(tsff_handle *h, const tsff_ats_config *cfg);
+int tsff_ats_spectrum(tsff_handle *h, const double *P, const double *e_amps /* device [rows] */, double lam, double amp1, double amp2, double *ThryE);
+
 /* ThomsonScatteringDiagnostic.__call__: ThryE/ThryI [B][1024].  noise_* may be NULL (= 0).
  * params: normalised leaves [B][NP]; fe: [B][nvx] when fe_mode == PER_LINEOUT else NULL. */
 int tsff_forward(tsff_handle *h, const double *params, const double *fe, const double *e_amps,

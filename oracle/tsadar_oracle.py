@@ -741,3 +741,53 @@ def form_factor_2d(lam_range, npts, lam_shift, sa_deg, num_grad_points, p, vx, f
     PsOmg = (S_ion + S_ele) * (1 + 2 * omgdop / omgL) * RE**2 * ne[:, None, None]
     lams = 2 * np.pi * C / omgs
     return PsOmg * 2 * np.pi * C / lams**2, lams[0, :, 0]
+
+
+# ---------------------------------------------------------------------------------------------
+# Angular (ARTS) instrument chain.  PARITY UNPINNED against the reference (its angular tests skip
+# when the golden arrays are absent); restated line by line from the cited sources.
+# ---------------------------------------------------------------------------------------------
+def ats_model(cfg, weights, P, lam_nm):
+    """FitModel.electron_spectrum, spectype "angular_full" (generate_spectra.py:193-216, iawoff == 0):
+    P [G, npts, n_angles] -> modlE [n_px, npts]."""
+    modl = weights @ np.mean(P, axis=0).T
+    filt = cfg["other"]["iawfilter"]
+    if filt[0]:
+        fb, fr = filt[3] - filt[2] / 2, filt[3] + filt[2] / 2
+        if cfg["other"]["lamrangE"][0] < fr and cfg["other"]["lamrangE"][1] > fb:
+            modl = np.where((fb < lam_nm) & (fr > lam_nm), modl * 10.0 ** (-filt[1]), modl)
+    return modl
+
+
+def add_ats_irf(cfg, ang_axis, lam_nm, modl):
+    """irf.py:5-47 (norm == 0): Gaussian "same" convolutions along the angular-pixel axis then the wavelength axis,
+    each angular pixel rescaled to the unconvolved maximum."""
+    wid = cfg["other"]["PhysParams"]["widIRF"]
+    s_lam, s_ang = wid["spect_FWHM_ele"] / 2.3548, wid["ang_FWHM_ele"] / 2.3548
+    o_lam = (np.amax(lam_nm) + np.amin(lam_nm)) / 2.0
+    o_ang = (np.amax(ang_axis) + np.amin(ang_axis)) / 2.0
+    g_lam = (1.0 / (s_lam * np.sqrt(2.0 * np.pi))) * np.exp(-((lam_nm - o_lam) ** 2.0) / (2.0 * s_lam**2.0))
+    g_ang = (1.0 / (s_ang * np.sqrt(2.0 * np.pi))) * np.exp(-((ang_axis - o_ang) ** 2.0) / (2.0 * s_ang**2.0))
+    y = np.array([np.convolve(modl[:, i], g_ang, "same") for i in range(modl.shape[1])])
+    y = np.array([np.convolve(y[:, i], g_lam, "same") for i in range(y.shape[1])])
+    return np.amax(modl, axis=1, keepdims=True) / np.amax(y, axis=1, keepdims=True) * y
+
+
+def reduce_ats_to_resunit(cfg, y, lam_nm, n_lam_out, e_amps, p):
+    """thomson_diagnostic.py:78-107.  e_amps [rows, 1] (prepare.py:169)."""
+    lam_step = round(y.shape[1] / n_lam_out)
+    ang_step = round(y.shape[0] / cfg["other"]["CCDsize"][0])
+    y = np.array([np.average(y[:, i : i + lam_step], axis=1) for i in range(0, y.shape[1], lam_step)])
+    y = np.array([np.average(y[:, i : i + ang_step], axis=1) for i in range(0, y.shape[1], ang_step)])
+    lam = np.array([np.average(lam_nm[i : i + lam_step], axis=0) for i in range(0, lam_nm.shape[0], lam_step)])
+    y = y[cfg["data"]["lineouts"]["start"] : cfg["data"]["lineouts"]["end"], :]
+    y = e_amps * y / np.amax(y, axis=1, keepdims=True)
+    y = np.where(lam < p["lam"], p["amp1"] * y, p["amp2"] * y)
+    return y, lam
+
+
+def ats_spectrum(cfg, weights, ang_axis, P, lam_nm, n_lam_out, e_amps, p):
+    """lam_nm = squeeze(lamAxisE) * 1e7 of the form factor (generate_spectra.py:191)."""
+    modl = ats_model(cfg, weights, P, lam_nm)
+    y = add_ats_irf(cfg, ang_axis, lam_nm, modl)
+    return reduce_ats_to_resunit(cfg, y, lam_nm, n_lam_out, e_amps, p)

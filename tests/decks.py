@@ -155,3 +155,27 @@ def deck_kat(kind):
     P["ion-1"]["A"] = {"val": 1.0, "active": False}
     P["general"]["lam"] = _p(526.5, False, 523.0, 528.0)
     return finish(cfg)
+
+
+def deck_angular(dim=1, nvx=64, ccd=(1024, 1024), start=90, end=950):
+    """ARTS deck: the numbers of tests/configs/arts1v_test_inputs.yaml / arts2v_test_defaults.yaml (Te 1.0, ne 0.4,
+    Z 8, A 14, lam 526.5, DLM m 2.5; lineouts 90:950, spect_FWHM_ele 0.9 nm, ang_FWHM_ele 1 deg), spectype
+    "angular_full" as tests/test_forward/test_angular_1v.py:58 sets it."""
+    cfg = copy.deepcopy(deck_1d(1, nvx, 2.5, fe_active=True))
+    P = cfg["parameters"]
+    P["electron"]["Te"] = _p(1.0, True, 0.01, 1.5)
+    P["electron"]["ne"] = _p(0.4, True, 0.001, 1.0)
+    P["ion-1"]["A"]["val"] = 14.0
+    P["general"]["lam"] = _p(526.5, True, 525.0, 528.0)
+    if dim == 2:
+        P["electron"]["fe"] = {"active": True, "type": "arbitrary", "dim": 2, "nvx": nvx,
+                               "params": {"init_m": 2.5, "learn_log": True}}
+        P["general"]["ud"]["angle"] = 20.0
+        P["general"]["Va"]["angle"] = -35.0
+    cfg["other"]["extraoptions"]["spectype"] = "angular_full"
+    cfg["other"]["PhysParams"]["widIRF"].update(spect_FWHM_ele=0.9, ang_FWHM_ele=1.0, spect_stddev_ele=0.9 / 2.3548)
+    cfg["other"]["CCDsize"] = list(ccd)
+    cfg["data"]["lineouts"] = {"type": "range", "start": start, "end": end, "skip": 20}
+    cfg = finish(cfg)
+    cfg["other"]["npts"] = 1024  # prepare.py:202 evaluates it before CCDsize is replaced by the reduced shape
+    return cfg

@@ -9,6 +9,7 @@ import pytest
 import decks
 import util
 from oracle import tsadar_oracle as orc
+from tsadar_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -592,3 +593,86 @@ def test_form_factor_2d_matches_oracle(torch_mod, kind, nv):
             Po, _ = orc.form_factor_2d(rng, 1024, 0.0, sa["sa"], 1, p, vx, fe2, ud_ang, va_ang, lam_index=idx)
             err = np.max(np.abs(P[b][:, idx, :] - Po) / np.abs(Po))
             assert err < 1e-7, (feature, b, err)
+
+
+def _angular_sa(cfg):
+    """tests/test_forward/test_angular_1v.py:53-60: the geometry is looked up as spectype "angular", then the deck is
+    switched to "angular_full"."""
+    from tsadar_amd import calibration
+
+    cfg["other"]["extraoptions"]["spectype"] = "angular"
+    sa = calibration.get_scattering_angles(cfg)
+    cfg["other"]["extraoptions"]["spectype"] = "angular_full"
+    sa["angAxis"] = calibration.angular_pixel_axis()
+    return sa
+
+
+@pytest.mark.parametrize("ccd,n_lam,start,end", [((1024, 1024), 1024, 90, 950), ((128, 256), 256, 10, 110)])
+def test_ats_instrument_chain_matches_oracle(torch_mod, ccd, n_lam, start, end):
+    """a16: angular_full weight-matrix product, add_ATS_IRF and reduce_ATS_to_resunit on the reference's own
+    calibration data (1024 x 241 weight matrix, non-uniform pixel angle axis) vs the oracle's line-by-line
+    restatement, full size and with 8 x 4 resolution units.  Both consume the same P[1, 1024, 241]."""
+    from tsadar_amd import calibration
+
+    cfg = decks.deck_angular(1, 64, ccd, start, end)
+    sa = _angular_sa(cfg)
+    assert sa["weights"].shape == (1024, 241) and sa["angAxis"].shape == (1024,)
+    eng = _engine(cfg, sa, fe_mode=L.FE_PER_LINEOUT)
+    normed = util.random_lineouts(cfg, 1, seed=5)
+    phys = orc.physical_params(cfg["parameters"], normed, True)
+    X = util.normed_to_matrix(phys, 1)
+    P = eng.form_factor(0, X, orc.dlm_fe(2.7, 64)[None, :])[0]
+    assert P.shape == (1, 1024, 241)
+    lam_step, ang_step = 1024 // n_lam, 1024 // ccd[0]
+    wid = cfg["other"]["PhysParams"]["widIRF"]
+    eng.ats_setup(sa["weights"], sa["angAxis"], wid["spect_FWHM_ele"] / 2.3548, wid["ang_FWHM_ele"] / 2.3548,
+                  lam_step, ang_step, start, end)
+    rows = end - start
+    e_amps = np.random.default_rng(3).uniform(0.5, 2.0, (rows, 1))
+    p = orc.lineout_params(phys, 0, 1)
+    E = eng.ats_spectrum(P, e_amps, p["lam"], p["amp1"], p["amp2"]).cpu().numpy()
+    lam_nm = np.linspace(*cfg["other"]["lamrangE"], 1024)
+    Eo, lam_o = orc.ats_spectrum(cfg, sa["weights"], sa["angAxis"], P.cpu().numpy(), lam_nm, n_lam, e_amps, p)
+    assert E.shape == Eo.shape == (rows, n_lam)
+    err = np.max(np.abs(E - Eo)) / np.max(np.abs(Eo))
+    assert err < 1e-10, err  # 12-sigma tap cut-off: 5e-32 relative
+    assert np.all(np.abs(E - Eo) <= 1e-9 * np.abs(Eo) + 1e-12)
+
+
+@pytest.mark.parametrize("dim", [1, 2])
+def test_angular_diagnostic_end_to_end(torch_mod, dim):
+    """ThomsonScatteringDiagnostic with spectype angular_full (tests/test_forward/test_angular_1v.py / _2v.py call
+    pattern: batch=False parameters, e_amps = [1]) for a 1-D DLM and a 2-D Arbitrary2V distribution function; the
+    1-D case is checked end to end against the oracle (form factor at 241 angles + instrument chain)."""
+    from tsadar_amd import ThomsonParams, calibration
+    from tsadar_amd.diagnostic import ThomsonScatteringDiagnostic
+
+    cfg = decks.deck_angular(dim, 256 if dim == 1 else 64)
+    sa = _angular_sa(cfg)
+    batch = dict(e_data=np.ones((1024, 1024)), i_data=np.ones((1024, 1024)), noise_e=np.array([0]), noise_i=np.array([0]),
+                 e_amps=np.array([1]), i_amps=np.array([1]))
+    diag = ThomsonScatteringDiagnostic(cfg, sa)
+    tp = ThomsonParams(cfg["parameters"], 1, batch=False, activate=True)
+    E, I, lamE, lamI = diag(tp, batch)
+    assert E.shape == (860, 1024) and np.all(np.isfinite(E)) and lamE.shape == (1024,)
+    amp = tp.physical_matrix()[0, [L.P_AMP1, L.P_AMP2]]
+    assert np.all(np.max(E, axis=1) <= np.max(amp) * (1 + 1e-12)) and np.all(np.max(E, axis=1) >= np.min(amp) * 0.5)
+    if dim == 1:
+        phys = orc.physical_params(cfg["parameters"], orc.init_normed_params(cfg["parameters"], 1, True), True)
+        p = orc.lineout_params(phys, 0, 1)
+        vx = orc.velocity_grid(256)
+        fe = orc.dlm_fe(float(p["m"]), 256)
+        Po, lam_cm = orc.form_factor(cfg["other"]["lamrangE"], 1024, 0.0, sa["sa"], 1, p, vx, fe)
+        Eo, lam_o = orc.ats_spectrum(cfg, sa["weights"], sa["angAxis"], Po, np.squeeze(lam_cm) * 1e7, 1024,
+                                     np.ones((860, 1)), p)
+        assert np.max(np.abs(E - Eo)) / np.max(np.abs(Eo)) < 1e-7
+        np.testing.assert_allclose(lamE, lam_o, rtol=1e-13)
+    else:
+        fe2 = tp()["electron"]["fe"]
+        vx = tp()["electron"]["v"]
+        assert fe2.shape == (64, 64) and abs(np.sum(fe2) * (vx[1] - vx[0]) ** 2 - 1.0) < 1e-12
+        eng = diag.engine(True)
+        P = eng.form_factor_2d(0, tp.physical_matrix(), fe2, 20.0, -35.0)[0].cpu().numpy()
+        p = orc.lineout_params(orc.physical_params(cfg["parameters"], orc.init_normed_params(cfg["parameters"], 1, True), True), 0, 1)
+        Eo, _ = orc.ats_spectrum(cfg, sa["weights"], sa["angAxis"], P, np.linspace(400, 700, 1024), 1024, np.ones((860, 1)), p)
+        assert np.max(np.abs(E - Eo)) / np.max(np.abs(Eo)) < 1e-10

@@ -1,5 +1,6 @@
 """Host-side logic of the drop-in layer (no GPU): parameter container, pytree helpers, static tables."""
 import numpy as np
+import pytest
 
 import decks
 import util
@@ -116,3 +117,40 @@ def test_binned_taps_equal_convolve_then_bin():
         xp = np.concatenate([np.zeros(pad), x, np.zeros(pad)])
         y = np.array([np.dot(hb, xp[pad + p * ppp + off: pad + p * ppp + off + hb.size]) for p in range(1024)])
         assert np.max(np.abs(y - ref)) < 1e-13 * ref.max()
+
+
+def test_angular_geometry_and_arbitrary_2v():
+    """ARTS calibration data (calibration.py:456-458, 483-491), Arbitrary2V generator (base.py:375-427) and the
+    oracle's instrument chain on a synthetic image: unit row maxima scaled by e_amps * amp1|amp2."""
+    from oracle import tsadar_oracle as orc
+    from tsadar_amd import ThomsonParams, calibration
+    from tsadar_amd import distribution as D
+
+    cfg = decks.deck_angular(2, 32, (128, 256), 10, 110)
+    cfg["other"]["extraoptions"]["spectype"] = "angular"
+    sa = calibration.get_scattering_angles(cfg)
+    cfg["other"]["extraoptions"]["spectype"] = "angular_full"
+    ang = calibration.angular_pixel_axis()
+    assert sa["sa"].shape == (241,) and sa["weights"].shape == (1024, 241) and ang.shape == (1024,)
+    assert np.all(np.diff(ang) > 0) and np.all(sa["weights"] >= 0)
+    # one_d geometry lookup is what the reference returns for "angular_full" (calibration.py:483)
+    assert calibration.get_scattering_angles(cfg)["sa"].shape == (10,)
+
+    tp = ThomsonParams(cfg["parameters"], 1, batch=False, activate=True)
+    fe, vx = tp()["electron"]["fe"], tp()["electron"]["v"]
+    assert fe.shape == (32, 32) and abs(np.sum(fe) * (vx[1] - vx[0]) ** 2 - 1) < 1e-13
+    # learn_log round trip reproduces the grid-normalised super-Gaussian
+    f_lin = D.arbitrary_2v(D.arbitrary_2v_init(2.5, 32, False), False)
+    np.testing.assert_allclose(fe, f_lin, rtol=1e-12)
+    with pytest.raises(NotImplementedError):
+        ThomsonParams(cfg["parameters"], 2, batch=True)
+
+    rng = np.random.default_rng(0)
+    lam_nm = np.linspace(400, 700, 1024)
+    P = np.exp(-0.5 * ((lam_nm[None, :, None] - 450 - 0.8 * np.arange(241)[None, None, :]) / 6.0) ** 2) + 1e-3
+    e_amps = rng.uniform(0.5, 2.0, (100, 1))
+    p = dict(lam=526.5, amp1=0.7, amp2=1.3)
+    E, lam = orc.ats_spectrum(cfg, sa["weights"], ang, P, lam_nm, 256, e_amps, p)
+    assert E.shape == (100, 256) and lam.shape == (256,)
+    peak = np.max(E / np.where(lam < 526.5, 0.7, 1.3), axis=1)
+    np.testing.assert_allclose(peak, e_amps[:, 0], rtol=1e-12)

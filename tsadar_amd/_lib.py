@@ -76,6 +76,24 @@ class TsffConfig(C.Structure):
     ]
 
 
+class TsffAtsConfig(C.Structure):
+    _fields_ = [
+        ("n_px", C.c_int32),
+        ("weights", c_double_p),
+        ("n_taps_ang", C.c_int32),
+        ("tap_off_ang", C.c_int32),
+        ("taps_ang", c_double_p),
+        ("n_taps_lam", C.c_int32),
+        ("tap_off_lam", C.c_int32),
+        ("taps_lam", c_double_p),
+        ("lam_step", C.c_int32),
+        ("ang_step", C.c_int32),
+        ("row_start", C.c_int32),
+        ("row_end", C.c_int32),
+        ("lam_axis", c_double_p),
+    ]
+
+
 _vp = C.c_void_p
 _SIGNATURES = {
     "tsff_abi_version": (C.c_int, []),
@@ -89,6 +107,8 @@ _SIGNATURES = {
     "tsff_chi_table": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
     "tsff_form_factor": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp]),
     "tsff_form_factor_2d": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, _vp]),
+    "tsff_ats_setup": (C.c_int, [_vp, C.POINTER(TsffAtsConfig)]),
+    "tsff_ats_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "tsff_forward": (C.c_int, [_vp] + [_vp] * 6 + [C.c_int32, _vp, _vp]),
     "tsff_loss_grad": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, _vp, _vp, _vp, _vp]),
     "tsff_array_loss": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, _vp, _vp, _vp, _vp, _vp]),

@@ -2,12 +2,17 @@
 
 Mirrors ``sa_lookup`` / ``get_scattering_angles`` of the reference
 (tsadar/utils/data_handling/calibration.py:9-214, 465-492): ten scattering angles per probe beam
-(finite collection aperture) and their relative weights.  Only the 1-D geometries are covered; the
-angular ("ARTS") weight matrix lives in a .mat file of the reference and is outside this path.
+(finite collection aperture) and their relative weights, plus the angular ("ARTS") geometry: 241 scattering
+angles, the 1024 x 241 pixel weight matrix and the calibrated angle of each pixel (data files
+``data/angleWghtsFredfine.mat`` / ``data/angsFRED.mat``, the reference's own calibration data).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 # beam: (first angle [deg], last angle [deg], weights[10])
 _BEAMS = {
@@ -37,4 +42,16 @@ def get_scattering_angles(config: dict) -> dict:
     """Scattering-angle dictionary for an input deck (calibration.py:465-492)."""
     if config["other"]["extraoptions"]["spectype"] != "angular":
         return sa_lookup(config["data"]["probe_beam"])
-    raise NotImplementedError("angular (ARTS) geometry is outside the 1-D form-factor path")
+    import scipy.io as sio
+
+    w = sio.loadmat(os.path.join(_DATA, "angleWghtsFredfine.mat"), variable_names="weightMatrix")["weightMatrix"]
+    return dict(sa=np.arange(19, 139.5, 0.5), weights=np.ascontiguousarray(w, dtype=np.float64))
+
+
+def angular_pixel_axis() -> np.ndarray:
+    """Calibrated scattering angle of each of the 1024 angular pixels: sas["angAxis"] of the reference
+    (calibration.py:456-458, prepare.py:136)."""
+    import scipy.io as sio
+
+    a = sio.loadmat(os.path.join(_DATA, "angsFRED.mat"), variable_names="angsFRED")["angsFRED"][0, :]
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1114,6 +1114,92 @@ __global__ __launch_bounds__(kThreads) void k_form_factor_2d(KStatic S, const do
 }
 
 // ------------------------------------------------------------------------------------------
+// Angular (ARTS) instrument chain: FitModel.electron_spectrum for spectype "angular_full"
+// (generate_spectra.py:193-216), add_ATS_IRF (irf.py:5-47), reduce_ATS_to_resunit
+// (thomson_diagnostic.py:78-107).  Five small kernels over [n_px x npts] images; none of them is hot.
+// ------------------------------------------------------------------------------------------
+// M[r][j] = filt[j] * sum_a Wt[r][a] * mean_g P[g][j][a]
+__global__ void k_ats_weights(const double* __restrict__ P, const double* __restrict__ Wt, const double* __restrict__ filt,
+                              int G, int npts, int NA, int npx, double* __restrict__ M) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (j >= npts) return;
+  double acc = 0.0;
+  for (int a = 0; a < NA; ++a) {
+    const double w = Wt[(size_t)r * NA + a];
+    if (w == 0.0) continue;
+    double m = 0.0;
+    for (int g = 0; g < G; ++g) m += P[((size_t)g * npts + j) * NA + a];
+    acc += w * (m / (double)G);
+  }
+  M[(size_t)r * npts + j] = filt ? acc * filt[j] : acc;
+}
+
+// "same" convolution along the angular-pixel axis (dim 0) or the wavelength axis (dim 1):
+// y[i] = sum_s taps[s] x[i + off + s], zero outside
+__global__ void k_ats_conv(const double* __restrict__ X, const double* __restrict__ taps, int nt, int off, int along_rows,
+                           int npx, int npts, double* __restrict__ Y) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (j >= npts) return;
+  double acc = 0.0;
+  if (along_rows) {
+    for (int s = 0; s < nt; ++s) {
+      const int rr = r + off + s;
+      if (rr >= 0 && rr < npx) acc += taps[s] * X[(size_t)rr * npts + j];
+    }
+  } else {
+    for (int s = 0; s < nt; ++s) {
+      const int jj = j + off + s;
+      if (jj >= 0 && jj < npts) acc += taps[s] * X[(size_t)r * npts + jj];
+    }
+  }
+  Y[(size_t)r * npts + j] = acc;
+}
+
+// per angular pixel: Y[r][:] *= max_j M[r][:] / max_j Y[r][:]   (irf.py:38)
+__global__ __launch_bounds__(kThreads) void k_ats_rownorm(const double* __restrict__ M, double* __restrict__ Y, int npts) {
+  __shared__ double red[8];
+  const int r = blockIdx.x;
+  double mm = -1e300, my = -1e300;
+  for (int j = threadIdx.x; j < npts; j += kThreads) {
+    mm = fmax(mm, M[(size_t)r * npts + j]);
+    my = fmax(my, Y[(size_t)r * npts + j]);
+  }
+  int dummy = 0;
+  block_argmax(mm, dummy, red);
+  dummy = 0;
+  block_argmax(my, dummy, red);
+  const double sc = mm / my;
+  for (int j = threadIdx.x; j < npts; j += kThreads) Y[(size_t)r * npts + j] *= sc;
+}
+
+// resolution-unit reduction + amplitude scaling (thomson_diagnostic.py:93-106): one workgroup per output row
+__global__ __launch_bounds__(kThreads) void k_ats_resunit(const double* __restrict__ Y, const double* __restrict__ lam_nm,
+                                                          int npts, int lam_step, int ang_step, int row_start,
+                                                          const double* __restrict__ e_amps, double lam, double amp1, double amp2,
+                                                          double* __restrict__ out) {
+  __shared__ double red[8];
+  const int R = blockIdx.x, nJ = npts / lam_step;
+  const int r0 = (row_start + R) * ang_step;
+  double mx = -1e300;
+  for (int J = threadIdx.x; J < nJ; J += kThreads) {
+    double acc = 0.0;
+    for (int dr = 0; dr < ang_step; ++dr)
+      for (int dj = 0; dj < lam_step; ++dj) acc += Y[(size_t)(r0 + dr) * npts + J * lam_step + dj];
+    acc /= (double)(ang_step * lam_step);
+    out[(size_t)R * nJ + J] = acc;
+    mx = fmax(mx, acc);
+  }
+  int dummy = 0;
+  block_argmax(mx, dummy, red);
+  for (int J = threadIdx.x; J < nJ; J += kThreads) {
+    double lb = 0.0;
+    for (int dj = 0; dj < lam_step; ++dj) lb += lam_nm[J * lam_step + dj];
+    lb /= (double)lam_step;
+    out[(size_t)R * nJ + J] = e_amps[R] * out[(size_t)R * nJ + J] / mx * (lb < lam ? amp1 : amp2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_fma_peak: micro-benchmark of the FP64 vector FMA rate (the roof this path is bound by): 16 independent
 // accumulators per lane, `iters` x 16 fused multiply-adds, enough wavefronts to fill every SIMD.
 // ------------------------------------------------------------------------------------------

@@ -60,3 +60,27 @@ def dlm(m: float, nvx: int) -> np.ndarray:
 def maxwellian(nvx: int) -> np.ndarray:
     """The reference's Maxwellian is DLM m = 2 (tests/configs/epw_inputs.yaml:13-21)."""
     return dlm(2.0, nvx)
+
+
+def arbitrary_2v_init(m: float, nvx: int, learn_log: bool) -> np.ndarray:
+    """Arbitrary2V.init_dlm (base.py:375-408): the stored parameter array fval [nvx, nvx] -- the square root of the
+    (optionally -log10 of the) grid-normalised 2-D super-Gaussian of order m with v_th = sqrt(2)."""
+    vx = velocity_grid(nvx)
+    vth = np.sqrt(2.0)
+    alpha = np.sqrt(3.0 * gamma(3.0 / m) / 2.0 / gamma(5.0 / m))
+    cst = m / (4.0 * np.pi * alpha**3.0 * gamma(3.0 / m))
+    f = cst / vth**3.0 * np.exp(-((np.sqrt(vx[:, None] ** 2.0 + vx[None, :] ** 2.0) / alpha / vth) ** m))
+    f = f / np.sum(f) / (vx[1] - vx[0]) ** 2.0
+    if learn_log:
+        f = -np.log10(f)
+    return np.sqrt(f)
+
+
+def arbitrary_2v(fval: np.ndarray, learn_log: bool) -> np.ndarray:
+    """Arbitrary2V.__call__ (base.py:413-427): fval -> normalised f_e(vx, vy)."""
+    nvx = fval.shape[-1]
+    vx = velocity_grid(nvx)
+    f = np.asarray(fval, dtype=np.float64) ** 2.0
+    if learn_log:
+        f = np.power(10.0, -f)
+    return f / np.sum(f) / (vx[1] - vx[0]) ** 2.0

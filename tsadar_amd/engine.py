@@ -117,8 +117,11 @@ class Engine:
         assert gen["Te_gradient"]["num_grad_points"] == gen["ne_gradient"]["num_grad_points"], \
             "Number of gradient points for Te and ne must be the same"  # generate_spectra.py:70-73
         fecfg = cfg["parameters"]["electron"]["fe"]
-        if fecfg.get("dim", 1) != 1:
-            raise NotImplementedError("2-D distribution functions are outside the 1-D form-factor path")
+        self.fe_dim = int(fecfg.get("dim", 1))
+        if self.fe_dim not in (1, 2):
+            raise NotImplementedError(f"Not implemented distribution dimension: {self.fe_dim}")  # ts_params.py:164
+        if self.fe_dim == 2 and fe_mode is None:
+            fe_mode = L.FE_PER_LINEOUT  # the 1-D tables are unused: only form_factor_2d / ats_spectrum run
         self.nvx = int(fecfg["nvx"])
 
         c = L.TsffConfig()
@@ -320,6 +323,45 @@ class Engine:
                                           float(ud_angle), float(va_angle), B, self._ptr(P))
         L.check(self.lib, self.h, rc)
         return P
+
+    def ats_setup(self, weights, ang_axis, stddev_lam, stddev_ang, lam_step=1, ang_step=1, row_start=0, row_end=None,
+                  irf_cutoff_sigmas=12.0):
+        """Static configuration of the angular (ARTS) instrument chain: weight matrix [n_px, n_angles], the calibrated
+        angle axis sas["angAxis"] [n_px] and the two Gaussian widths (FWHM / 2.3548, irf.py:23-24)."""
+        W = np.ascontiguousarray(weights, dtype=np.float64)
+        n_px = W.shape[0]
+        assert W.shape[1] == int(self._cfg_struct.n_angles)
+        lamE = wavelength_axis_nm(self.cfg["other"]["lamrangE"], self.npts)
+        ta, da = gaussian_taps(np.asarray(ang_axis, dtype=np.float64), float(stddev_ang), irf_cutoff_sigmas)
+        ta, offa = binned_taps(ta, da, 1)
+        tl, dl = gaussian_taps(lamE, float(stddev_lam), irf_cutoff_sigmas)
+        tl, offl = binned_taps(tl, dl, 1)
+        c = L.TsffAtsConfig()
+        c.n_px = n_px
+        keep = []
+        a, c.weights = _as_c(W, np.float64); keep.append(a)
+        a, c.taps_ang = _as_c(ta, np.float64); keep.append(a)
+        a, c.taps_lam = _as_c(tl, np.float64); keep.append(a)
+        a, c.lam_axis = _as_c(lamE, np.float64); keep.append(a)
+        c.n_taps_ang, c.tap_off_ang, c.n_taps_lam, c.tap_off_lam = ta.size, offa, tl.size, offl
+        c.lam_step, c.ang_step = int(lam_step), int(ang_step)
+        c.row_start = int(row_start)
+        c.row_end = int(row_end if row_end is not None else n_px // ang_step)
+        L.check(self.lib, self.h, self.lib.tsff_ats_setup(self.h, C.byref(c)))
+        self._ats_shape = (c.row_end - c.row_start, self.npts // int(lam_step))
+
+    def ats_spectrum(self, P, e_amps, lam, amp1, amp2):
+        """P [G, npts, n_angles] (one image) -> ThryE [rows, npts / lam_step]."""
+        torch = self.torch
+        Pd = self.dev(P)
+        ea = self.dev(np.broadcast_to(np.asarray(e_amps, dtype=np.float64).reshape(-1), (self._ats_shape[0],)).copy()
+                      if not torch.is_tensor(e_amps) else e_amps.reshape(-1))
+        assert ea.numel() == self._ats_shape[0]
+        out = torch.empty(self._ats_shape, dtype=torch.float64, device=self.device)
+        self._sync_stream()
+        rc = self.lib.tsff_ats_spectrum(self.h, self._ptr(Pd), self._ptr(ea), float(lam), float(amp1), float(amp2), self._ptr(out))
+        L.check(self.lib, self.h, rc)
+        return out
 
     def forward(self, params, e_amps, i_amps, noise_e=None, noise_i=None, fe=None):
         torch = self.torch

@@ -32,6 +32,9 @@ class LossFunction:
         self.multiplex_ang = isinstance(cfg["data"].get("shotnum"), list)
         if self.multiplex_ang:
             raise NotImplementedError("multiplexed angular fits are outside the 1-D form-factor path")
+        if "angular" in cfg["other"]["extraoptions"]["spectype"]:
+            raise NotImplementedError("the gradient of the angular (ARTS) model is not built: forward only "
+                                      "(ThomsonScatteringDiagnostic)")
         self.ts_diag = ThomsonScatteringDiagnostic(cfg, scattering_angles=scattering_angles)
         self.distributed = distributed
         self.pg = process_group

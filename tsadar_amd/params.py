@@ -133,6 +133,20 @@ class ThomsonParams:
         g = param_cfg["general"]
         for k in GENERAL_KEYS:
             X[:, _GENERAL_SLOT[k]] = self._init(g[k]["val"], _GENERAL_SLOT[k])
+        # 2-D distribution function (ts_params.py:152-163): one shared table, never batched
+        self.fe_dim = int(el.get("fe", {}).get("dim", 1))
+        self.fval2d = None
+        if self.fe_dim == 2:
+            from . import distribution as D
+
+            if batch:
+                raise NotImplementedError(
+                    "Batch mode not implemented for 2D distributions as a precautionary measure against memory issues")
+            fe = el["fe"]
+            if str(fe["type"]).casefold() != "arbitrary":
+                raise NotImplementedError(f"2D distribution type not built on the MI355X path: {fe['type']}")
+            self.learn_log = bool(fe["params"]["learn_log"])
+            self.fval2d = D.arbitrary_2v_init(float(fe["params"]["init_m"]), int(fe["nvx"]), self.learn_log)
         self.X = X  # [B, NP] normalised leaves, engine layout
 
     def _init(self, val, slot):
@@ -210,6 +224,9 @@ class ThomsonParams:
             vx = np.tile(D.velocity_grid(nvx)[None, :], (len(m), 1))
             out["electron"]["fe"] = fe if self.batch else fe[0]
             out["electron"]["v"] = vx if self.batch else vx[0]
+        if self.fe_dim == 2:
+            out["electron"]["fe"] = D.arbitrary_2v(self.fval2d, self.learn_log)
+            out["electron"]["v"] = D.velocity_grid(nvx)
         return out
 
     def get_fitted_params(self, param_cfg) -> tuple:
