@@ -250,8 +250,10 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": ("configs[2]: batch 4096 EPW+IAW spectra forward+adjoint (loss+grad as inside the L-BFGS fit loop), "
-                         "6 free params {Te, ne, Ti, Va, lam, amp1}, Maxwellian f_e (shared W table)")
+            "workload": (("configs[2]: batch 4096 EPW+IAW spectra forward+adjoint (loss+grad as inside the L-BFGS fit loop), "
+                          "6 free params {Te, ne, Ti, Va, lam, amp1}, Maxwellian f_e (shared W table)") if not args.dlm else
+                         ("configs[2] variant: batch 4096 EPW+IAW spectra forward+adjoint, 6 free params {Te, ne, m, amp1, amp2, lam} "
+                          "of the reference's 1-D fit test, per-lineout DLM f_e (W and dW/dm tables rebuilt every step)"))
             if not args.forward_only else "configs[1]-like: forward-only EPW+IAW spectra, Maxwellian f_e",
             "lineouts_per_gpu": B,
             "global_batch": B * world,

@@ -233,6 +233,8 @@ int tsff_kernel_times(tsff_handle *h, float *ms, int32_t max_n, int32_t *n_out);
 /* micro-benchmark: sustained FP64 vector FMA rate of this device in TFLOP/s (the roof the path is bound by;
  * AMD's datasheet figure for MI355X is 78.6).  Synchronous. */
 int tsff_fp64_fma_peak(tsff_handle *h, double *tflops);
+/* the same on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the roof of k_wgemm */
+int tsff_fp64_mfma_peak(tsff_handle *h, double *tflops);
 
 #ifdef __cplusplus
 }

@@ -791,3 +791,38 @@ def ats_spectrum(cfg, weights, ang_axis, P, lam_nm, n_lam_out, e_amps, p):
     modl = ats_model(cfg, weights, P, lam_nm)
     y = add_ats_irf(cfg, ang_axis, lam_nm, modl)
     return reduce_ats_to_resunit(cfg, y, lam_nm, n_lam_out, e_amps, p)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-D distribution-function generators (PARITY UNPINNED: no reference fixture exists for them).
+# ---------------------------------------------------------------------------------------------
+def spherical_harmonics_fe(dist_cfg):
+    """SphericalHarmonics.__init__ + __call__ (spherical_harmonics.py:199-243, 267-318) for flm_type "mora-yahi"
+    (FLM_MY, :95-114).  jax.scipy.special.sph_harm(m, n, theta=azimuth, phi=polar) is restated with
+    scipy.special.sph_harm_y(n, m, polar, azimuth); the polar angle arctan2(vy, vx) is negative for vy < 0, where jax
+    builds P_l^m from sqrt(1 - cos^2) >= 0, i.e. from |polar|."""
+    from scipy.special import gamma, sph_harm_y
+
+    p = dist_cfg["params"]
+    nvx = dist_cfg["nvx"]
+    vx = velocity_grid(nvx)
+    vmax = 6.0 * 1.05 * np.sqrt(2.0)
+    dvr = vmax / p["nvr"]
+    vr = np.linspace(dvr / 2, vmax - dvr / 2, p["nvr"])
+    X, Y = np.meshgrid(vx, vx)
+    th, az, r = np.arctan2(Y, X), np.arccos(Y / np.abs(Y)), np.sqrt(X**2 + Y**2)
+    x = (p["init_m"] - 2.0) / 3.0
+    m = sigmoid(np.log(1e-2 + x / (1 - x + 1e-2))) * 3.0 + 2.0
+    v0 = 1.0 / np.sqrt(gamma(5.0 / m) / 3.0 / gamma(3.0 / m))
+    f00 = m / (4 * np.pi * gamma(3.0 / m)) / v0**3.0 * np.exp(-((vr / v0) ** m))
+    f00 /= np.sum(f00 * 4 * np.pi * vr**2.0) * (vr[1] - vr[0])
+    f = np.interp(r, vr, f00, right=1e-16)
+    for i in range(1, p["Nl"] + 1):
+        for j in range(i + 1):
+            LT = p["LTx"] if j == 0 else p["LTy"]
+            ve = gamma(5.0 / m) / 3 / gamma(3.0 / m)
+            coeff = (m / 2 * vr**m - 5 * m / 12 * gamma(8 / m) / gamma(6 / m) * vr ** (m - 2) - 1.5) * (vr / ve) ** 4.0
+            flm = coeff / 10 ** np.log10(LT) * f00
+            f = f + np.interp(r, vr, flm, right=1e-32) * np.real(sph_harm_y(i, j, np.abs(th), az))
+    f = np.maximum(f, 1e-32)
+    return f / (np.sum(f) * (vx[1] - vx[0]) ** 2)

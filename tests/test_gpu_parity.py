@@ -639,8 +639,8 @@ def test_ats_instrument_chain_matches_oracle(torch_mod, ccd, n_lam, start, end):
     assert np.all(np.abs(E - Eo) <= 1e-9 * np.abs(Eo) + 1e-12)
 
 
-@pytest.mark.parametrize("dim", [1, 2])
-def test_angular_diagnostic_end_to_end(torch_mod, dim):
+@pytest.mark.parametrize("dim,fe_type", [(1, "dlm"), (2, "arbitrary"), (2, "sphericalharmonic")])
+def test_angular_diagnostic_end_to_end(torch_mod, dim, fe_type):
     """ThomsonScatteringDiagnostic with spectype angular_full (tests/test_forward/test_angular_1v.py / _2v.py call
     pattern: batch=False parameters, e_amps = [1]) for a 1-D DLM and a 2-D Arbitrary2V distribution function; the
     1-D case is checked end to end against the oracle (form factor at 241 angles + instrument chain)."""
@@ -648,6 +648,9 @@ def test_angular_diagnostic_end_to_end(torch_mod, dim):
     from tsadar_amd.diagnostic import ThomsonScatteringDiagnostic
 
     cfg = decks.deck_angular(dim, 256 if dim == 1 else 64)
+    if fe_type == "sphericalharmonic":  # tests/configs/arts2d_test_inputs.yaml:85-97
+        cfg["parameters"]["electron"]["fe"] = {"active": True, "dim": 2, "type": "sphericalharmonic", "nvx": 64, "params": {
+            "flm_type": "mora-yahi", "init_m": 2.2, "LTx": 225000.0, "LTy": 400000.0, "Nl": 1, "nvr": 64}}
     sa = _angular_sa(cfg)
     batch = dict(e_data=np.ones((1024, 1024)), i_data=np.ones((1024, 1024)), noise_e=np.array([0]), noise_i=np.array([0]),
                  e_amps=np.array([1]), i_amps=np.array([1]))

@@ -1,4 +1,6 @@
 """Host-side logic of the drop-in layer (no GPU): parameter container, pytree helpers, static tables."""
+import copy
+
 import numpy as np
 import pytest
 
@@ -154,3 +156,33 @@ def test_angular_geometry_and_arbitrary_2v():
     assert E.shape == (100, 256) and lam.shape == (256,)
     peak = np.max(E / np.where(lam < 526.5, 0.7, 1.3), axis=1)
     np.testing.assert_allclose(peak, e_amps[:, 0], rtol=1e-12)
+
+
+def test_spherical_harmonics_generator():
+    """SphericalHarmonics 2-D f_e (tests/configs/arts2d_test_inputs.yaml numbers: Mora-Yahi l = 1 harmonics) vs the
+    oracle's restatement through scipy's sph_harm_y; normalisation, dipole asymmetry, error paths."""
+    from oracle import tsadar_oracle as orc
+
+    dc = {"nvx": 128, "dim": 2, "type": "sphericalharmonic", "active": True,
+          "params": {"flm_type": "mora-yahi", "init_m": 2.2, "LTx": 225000.0, "LTy": 400000.0, "Nl": 1, "nvr": 64}}
+    sh = D.SphericalHarmonics(dc)
+    f = sh()
+    fo = orc.spherical_harmonics_fe(dc)
+    np.testing.assert_allclose(f, fo, rtol=1e-11, atol=1e-40)
+    dv = sh.vx[1] - sh.vx[0]
+    assert abs(np.sum(f) * dv * dv - 1.0) < 1e-13
+    assert abs(sh.get_unnormed_m() - 2.2239479449367296) < 1e-12          # Q6 round trip of init_m = 2.2
+    assert np.abs(f - f[:, ::-1]).max() > 1e-4 * f.max()                 # heat-flux dipole breaks the symmetry
+    up = sh.get_unnormed_params()["flm"]
+    assert set(up[1].keys()) == {0, 1} and up[0][0].shape == (64,)
+    dc2 = copy.deepcopy(dc)
+    dc2["params"]["flm_type"] = "arbitrary"
+    f2 = D.SphericalHarmonics(dc2)()
+    np.testing.assert_allclose(f2, f2[::-1, ::-1], rtol=1e-12)           # zero-initialised harmonics: isotropic
+    dc2["params"]["flm_type"] = "nn"
+    with pytest.raises(NotImplementedError):
+        D.SphericalHarmonics(dc2)
+    cfg = decks.deck_angular(2, 128)
+    cfg["parameters"]["electron"]["fe"] = dc
+    tp = ThomsonParams(cfg["parameters"], 1, batch=False, activate=True)
+    np.testing.assert_allclose(tp()["electron"]["fe"], f, rtol=0, atol=0)

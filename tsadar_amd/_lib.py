@@ -115,6 +115,7 @@ _SIGNATURES = {
     "tsff_enable_timing": (C.c_int, [_vp, C.c_int32]),
     "tsff_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "tsff_fp64_fma_peak": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "tsff_fp64_mfma_peak": (C.c_int, [_vp, C.POINTER(C.c_double)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

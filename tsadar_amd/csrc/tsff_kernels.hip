@@ -289,57 +289,96 @@ __global__ __launch_bounds__(kThreads) void k_fe_vectors(KStatic S, const double
   if (tid == 0) { cst[2 * b] = c0; cst[2 * b + 1] = c1; }
 }
 
-// k_wgemm: W[b][q] = c0_b + sum_i Lg[q][i] (A_b[i] + xi2[q] s_b[i]) and the same for d/dm.
-// 64 (q) x 64 (vectors = 16 lineouts x 4) tile per 256-thread workgroup, 4 x 4 register tile per thread,
-// K = 1024 in steps of 16 through LDS.  FP64 VALU FMAs (no MFMA: same peak on this chip, and the rest of the
-// path is VALU anyway).
-constexpr int kGM = 64, kGN = 64, kGK = 16;
-__global__ __launch_bounds__(kThreads) void k_wgemm(const double* __restrict__ Lg, const double* __restrict__ X,
+// k_wgemm: W[b][q] = c0_b + sum_i Lg[q][i] (A_b[i] + xi2[q] s_b[i]) and the same for d/dm: the GEMM
+// C[v][q] = sum_k X[v][k] Lg[q][k] (v = 4 vectors per lineout, M = 4B, N = 1640, K = 1024) on the FP64 matrix
+// cores (v_mfma_f64_16x16x4_f64).  256 threads = 2 x 2 wavefronts, 64 x 64 per wavefront (4 x 4 MFMA tiles, 64
+// accumulator doubles per lane), 128 (vectors = 32 lineouts) x 128 (q) per workgroup, K in chunks of 16 staged
+// K-major in LDS with the next chunk prefetched into registers.  Inside every 16-row MFMA tile the rows are ordered
+// (component, lineout): a lane's four accumulators (rows (lane>>4) + 4 reg) are then (A, s, dA/dm, ds/dm)·Lg of ONE
+// lineout and 16 consecutive q sit on 16 consecutive lanes, so the epilogue needs no shuffle and writes 128-B runs.
+constexpr int kGM = 128, kGN = 128, kGK = 16, kGP = 132;  // kGP: LDS row pitch in doubles
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kThreads, 2) void k_wgemm(const double* __restrict__ Lg, const double* __restrict__ X,
                                                     const double* __restrict__ cst, const double* __restrict__ xi2,
                                                     int B, double* __restrict__ W, double* __restrict__ Wm) {
-  __shared__ double As[kGK][kGM + 2];
-  __shared__ double Bs[kGK][kGN + 2];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int q0 = blockIdx.x * kGM, b0 = blockIdx.y * (kGN / 4);
-  double acc[4][4];
+  __shared__ double Xs[2][kGK][kGP];  // double-buffered: one barrier per K chunk
+  __shared__ double Ls[2][kGK][kGP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: workgroup L runs on XCD L % 8; the 13 q-tiles that share one X tile (and every Lg tile) are
+  // given to the same XCD so that X is fetched into one L2 only.  Grid = 8 * ceil(nM / 8) * nQ workgroups.
+  constexpr int nQ = (kNXi2 + kGN - 1) / kGN;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int mtile = xcd + 8 * (jx / nQ), qtile = jx % nQ;
+  if (mtile * (kGM / 4) >= B) return;
+  const int q0 = qtile * kGN, b0 = mtile * (kGM / 4);
+  // staging: thread -> LDS row lr, kGK/2 consecutive k starting at lk
+  const int lr = tid >> 1, lk = (tid & 1) * (kGK / 2);
+  constexpr int kPF = kGK / 4;  // double2 loads per thread and operand
+  const int sb = b0 + (lr >> 4) * 4 + (lr & 3), sc = (lr >> 2) & 3;  // lineout / component of X row lr
+  const double* __restrict__ xrow = X + ((size_t)min(sb, B - 1) * 4 + sc) * kNXi1 + lk;
+  const double* __restrict__ lrow = Lg + (size_t)min(q0 + lr, kNXi2 - 1) * kNXi1 + lk;
+  mfma_d4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-  const int lr = tid >> 2, lk = (tid & 3) * 4;  // this thread stages row lr, columns lk..lk+3 of both tiles
-  const int qa = q0 + lr;
-  const int bv = b0 + (lr >> 2), cv = lr & 3;
-  const double* __restrict__ arow = Lg + (size_t)min(qa, kNXi2 - 1) * kNXi1 + lk;
-  const double* __restrict__ brow = X + ((size_t)min(bv, B - 1) * 4 + cv) * kNXi1 + lk;
-  const bool aok = qa < kNXi2, bok = bv < B;
-  for (int k0 = 0; k0 < kNXi1; k0 += kGK) {
-    const double2 a0 = *reinterpret_cast<const double2*>(arow + k0), a1 = *reinterpret_cast<const double2*>(arow + k0 + 2);
-    const double2 c0 = *reinterpret_cast<const double2*>(brow + k0), c1 = *reinterpret_cast<const double2*>(brow + k0 + 2);
-    __syncthreads();
-    As[lk][lr] = aok ? a0.x : 0.0; As[lk + 1][lr] = aok ? a0.y : 0.0; As[lk + 2][lr] = aok ? a1.x : 0.0; As[lk + 3][lr] = aok ? a1.y : 0.0;
-    Bs[lk][lr] = bok ? c0.x : 0.0; Bs[lk + 1][lr] = bok ? c0.y : 0.0; Bs[lk + 2][lr] = bok ? c1.x : 0.0; Bs[lk + 3][lr] = bok ? c1.y : 0.0;
-    __syncthreads();
+    for (int j = 0; j < 4; ++j) acc[i][j] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+  double2 px[kPF], pl[kPF];
 #pragma unroll
-    for (int k = 0; k < kGK; ++k) {
+  for (int j = 0; j < kPF; ++j) {
+    px[j] = *reinterpret_cast<const double2*>(xrow + 2 * j);
+    pl[j] = *reinterpret_cast<const double2*>(lrow + 2 * j);
+  }
+#pragma unroll
+  for (int j = 0; j < kPF; ++j) {
+    Xs[0][lk + 2 * j][lr] = px[j].x; Xs[0][lk + 2 * j + 1][lr] = px[j].y;
+    Ls[0][lk + 2 * j][lr] = pl[j].x; Ls[0][lk + 2 * j + 1][lr] = pl[j].y;
+  }
+  __syncthreads();
+  const int fr = lane & 15, fk = lane >> 4;
+  int cur = 0;
+  for (int k0 = 0; k0 < kNXi1; k0 += kGK, cur ^= 1) {
+    const bool more = k0 + kGK < kNXi1;
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < kPF; ++j) {
+        px[j] = *reinterpret_cast<const double2*>(xrow + k0 + kGK + 2 * j);
+        pl[j] = *reinterpret_cast<const double2*>(lrow + k0 + kGK + 2 * j);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < kGK; ks += 4) {
       double a[4], c[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; c[i] = Bs[k][tx * 4 + i]; }
+      for (int i = 0; i < 4; ++i) {
+        a[i] = Xs[cur][ks + fk][wm * 64 + i * 16 + fr];
+        c[i] = Ls[cur][ks + fk][wn * 64 + i * 16 + fr];
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(a[i], c[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], c[j], acc[i][j], 0, 0, 0);
     }
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < kPF; ++j) {
+        Xs[cur ^ 1][lk + 2 * j][lr] = px[j].x; Xs[cur ^ 1][lk + 2 * j + 1][lr] = px[j].y;
+        Ls[cur ^ 1][lk + 2 * j][lr] = pl[j].x; Ls[cur ^ 1][lk + 2 * j + 1][lr] = pl[j].y;
+      }
+    }
+    __syncthreads();
   }
-  const int bb = b0 + tx;
-  if (bb < B) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int bb = b0 + (wm * 4 + i) * 4 + fk;
+    if (bb >= B) continue;
     const double c0 = cst[2 * bb], c1 = cst[2 * bb + 1];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = q0 + ty * 4 + i;
+    for (int j = 0; j < 4; ++j) {
+      const int q = q0 + wn * 64 + j * 16 + fr;
       if (q < kNXi2) {
         const double x2 = xi2[q];
-        W[(size_t)bb * kNXi2 + q] = c0 + acc[i][0] + x2 * acc[i][1];
-        Wm[(size_t)bb * kNXi2 + q] = c1 + acc[i][2] + x2 * acc[i][3];
+        W[(size_t)bb * kNXi2 + q] = c0 + acc[i][j][0] + x2 * acc[i][j][1];
+        Wm[(size_t)bb * kNXi2 + q] = c1 + acc[i][j][2] + x2 * acc[i][j][3];
       }
     }
   }
@@ -1214,6 +1253,22 @@ __global__ __launch_bounds__(kThreads) void k_fma_peak(double* __restrict__ out,
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < 16; ++i) s += acc[i];
+  out[(size_t)blockIdx.x * kThreads + threadIdx.x] = s;
+}
+
+// the same for the FP64 matrix cores: 8 independent 16x16 accumulator tiles per wavefront, `iters` x 8 v_mfma_f64_16x16x4_f64
+__global__ __launch_bounds__(kThreads) void k_mfma_peak(double* __restrict__ out, int iters, double a, double b) {
+  mfma_d4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+  const double x = a + 1e-9 * threadIdx.x, y = b + 1e-9 * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[(size_t)blockIdx.x * kThreads + threadIdx.x] = s;
 }
 

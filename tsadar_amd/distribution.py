@@ -84,3 +84,102 @@ def arbitrary_2v(fval: np.ndarray, learn_log: bool) -> np.ndarray:
     if learn_log:
         f = np.power(10.0, -f)
     return f / np.sum(f) / (vx[1] - vx[0]) ** 2.0
+
+
+# ---------------------------------------------------------------------------------------------
+# SphericalHarmonics (spherical_harmonics.py:150-318): f(vx, vy) = f00(|v|) + sum_{l<=Nl, m<=l} f_lm(|v|) Re Y_l^m.
+# The reference evaluates jax.scipy.special.sph_harm(m, l, azimuth = arccos(vy/|vy|), polar = arctan2(vy, vx)); with
+# the azimuth in {0, pi} and the associated Legendre functions built from sqrt(1 - cos^2) (Condon-Shortley phase),
+# Re Y_l^m = N_lm P_l^m(cos th) cos(m az), P_l^m evaluated with sin = |sin th|.  Parameters: the super-Gaussian
+# order m of f00 (sigmoid-activated like every other leaf) and the radial functions f_lm: "mora-yahi" (one
+# log10 gradient length per harmonic) or "arbitrary" (two free arrays per harmonic).  flm_type "nn" needs the
+# reference's equinox MLP initialisation (jax PRNG) and is not built.
+# ---------------------------------------------------------------------------------------------
+def _assoc_legendre(l: int, m: int, x: np.ndarray) -> np.ndarray:
+    """P_l^m(x) with the Condon-Shortley phase, sin = sqrt(1 - x^2) >= 0 (scipy.special.lpmv convention)."""
+    from scipy.special import lpmv
+
+    return lpmv(m, l, x)
+
+
+def real_sph_harm(l: int, m: int, azimuth: np.ndarray, polar: np.ndarray) -> np.ndarray:
+    from math import factorial
+
+    norm = np.sqrt((2 * l + 1) / (4 * np.pi) * factorial(l - m) / factorial(l + m))
+    return norm * _assoc_legendre(l, m, np.cos(polar)) * np.cos(m * azimuth)
+
+
+class SphericalHarmonics:
+    """Host mirror of the reference class: ``__call__()`` -> f_e[nvx, nvx]; ``vx``; ``get_unnormed_params()``."""
+
+    def __init__(self, dist_cfg: dict):
+        p = dist_cfg["params"]
+        self.nvx = int(dist_cfg["nvx"])
+        self.vx = velocity_grid(self.nvx)
+        vmax = 6.0 * 1.05 * np.sqrt(2.0)
+        nvr = int(p["nvr"])
+        dvr = vmax / nvr
+        self.vr = np.linspace(dvr / 2, vmax - dvr / 2, nvr)
+        vx, vy = np.meshgrid(self.vx, self.vx)
+        self.th = np.arctan2(vy, vx)
+        self.phi = np.arccos(vy / np.abs(vy))
+        self.vr_vxvy = np.sqrt(vx**2 + vy**2)
+        self.Nl = int(p["Nl"])
+        self.m_scale, self.m_shift = 3.0, 2.0
+        x = (float(p["init_m"]) - self.m_shift) / self.m_scale
+        self.normed_m = np.log(1e-2 + x / (1 - x + 1e-2))
+        self.flm_type = str(p.get("flm_type", "arbitrary")).casefold()
+        self.flm = {}
+        for l in range(1, self.Nl + 1):
+            for m in range(l + 1):
+                if self.flm_type == "mora-yahi":
+                    if l != 1:
+                        raise NotImplementedError("Mora-Yahi only supports l=1, m=0 and l=1, m=1")
+                    self.flm[(l, m)] = {"log_10_LT": np.log10(p["LTx"] if m == 0 else p["LTy"])}
+                elif self.flm_type == "arbitrary":
+                    self.flm[(l, m)] = {"flm_sign": np.zeros(nvr), "flm_mag": np.zeros(nvr)}
+                elif self.flm_type == "nn":
+                    raise NotImplementedError("flm_type 'nn' (equinox MLP radial functions) is not built")
+                else:
+                    raise NotImplementedError(f"Unknown flm_type: {p.get('flm_type')}")
+
+    def get_unnormed_m(self) -> float:
+        return 1.0 / (1.0 + np.exp(-self.normed_m)) * self.m_scale + self.m_shift
+
+    def get_f00(self) -> np.ndarray:
+        m = self.get_unnormed_m()
+        v0 = 1.0 / np.sqrt(gamma(5.0 / m) / 3.0 / gamma(3.0 / m))
+        f00 = m / (4 * np.pi * gamma(3.0 / m)) / v0**3.0 * np.exp(-((self.vr / v0) ** m))
+        return f00 / (np.sum(f00 * 4 * np.pi * self.vr**2.0) * (self.vr[1] - self.vr[0]))
+
+    def radial(self, l: int, m: int, f00: np.ndarray) -> np.ndarray:
+        prm = self.flm[(l, m)]
+        if self.flm_type == "mora-yahi":  # FLM_MY.__call__, Mora & Yahi 1982 eq. 3
+            mf = self.get_unnormed_m()
+            ve = gamma(5.0 / mf) / 3 / gamma(3.0 / mf)
+            lam_v = (self.vr / ve) ** 4.0
+            coeff = (mf / 2 * self.vr**mf - 5 * mf / 12 * gamma(8 / mf) / gamma(6 / mf) * self.vr ** (mf - 2) - 1.5) * lam_v
+            return coeff / 10 ** prm["log_10_LT"] * f00
+        nvr = self.vr.size  # ArbitraryVr.__call__
+        w = np.hanning(nvr // 4)
+        w = w / w.sum()
+        sm = lambda a: np.convolve(a, w, mode="same")
+        sign = np.tanh(sm(prm["flm_sign"]))
+        mag = -(1.0 / (1.0 + np.exp(-sm(prm["flm_mag"])))) * 10
+        return 10**mag * sign
+
+    def get_unnormed_params(self) -> dict:
+        f00 = self.get_f00()
+        out = {0: {0: f00}, 1: {}}
+        for (l, m) in self.flm:
+            out.setdefault(l, {})[m] = self.radial(l, m, f00)
+        return {"flm": out}
+
+    def __call__(self) -> np.ndarray:
+        f00 = self.get_f00()
+        f = np.interp(self.vr_vxvy, self.vr, f00, right=1e-16)
+        for (l, m) in self.flm:
+            flm = np.interp(self.vr_vxvy, self.vr, self.radial(l, m, f00), right=1e-32)
+            f = f + flm * real_sph_harm(l, m, self.phi, self.th)
+        f = np.maximum(f, 1e-32)
+        return f / (np.sum(f) * (self.vx[1] - self.vx[0]) ** 2)

@@ -455,6 +455,12 @@ class Engine:
         L.check(self.lib, self.h, self.lib.tsff_fp64_fma_peak(self.h, C.byref(v)))
         return float(v.value)
 
+    def fp64_mfma_peak_tflops(self) -> float:
+        """Measured FP64 matrix-core (v_mfma_f64_16x16x4_f64) rate of this device (micro-benchmark, TFLOP/s)."""
+        v = C.c_double()
+        L.check(self.lib, self.h, self.lib.tsff_fp64_mfma_peak(self.h, C.byref(v)))
+        return float(v.value)
+
     def enable_timing(self, ring: int = 256):
         """Record one HIP event pair around every main-kernel launch (ring of ``ring`` launches)."""
         L.check(self.lib, self.h, self.lib.tsff_enable_timing(self.h, int(ring)))

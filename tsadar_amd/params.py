@@ -143,10 +143,14 @@ class ThomsonParams:
                 raise NotImplementedError(
                     "Batch mode not implemented for 2D distributions as a precautionary measure against memory issues")
             fe = el["fe"]
-            if str(fe["type"]).casefold() != "arbitrary":
-                raise NotImplementedError(f"2D distribution type not built on the MI355X path: {fe['type']}")
-            self.learn_log = bool(fe["params"]["learn_log"])
-            self.fval2d = D.arbitrary_2v_init(float(fe["params"]["init_m"]), int(fe["nvx"]), self.learn_log)
+            self.sph = None
+            if "sph" in str(fe["type"]).casefold():  # ts_params.py:157-158
+                self.sph = D.SphericalHarmonics(fe)
+            elif str(fe["type"]).casefold() == "arbitrary":
+                self.learn_log = bool(fe["params"]["learn_log"])
+                self.fval2d = D.arbitrary_2v_init(float(fe["params"]["init_m"]), int(fe["nvx"]), self.learn_log)
+            else:
+                raise NotImplementedError(f"Unknown 2D distribution type: {fe['type']}")
         self.X = X  # [B, NP] normalised leaves, engine layout
 
     def _init(self, val, slot):
@@ -225,7 +229,7 @@ class ThomsonParams:
             out["electron"]["fe"] = fe if self.batch else fe[0]
             out["electron"]["v"] = vx if self.batch else vx[0]
         if self.fe_dim == 2:
-            out["electron"]["fe"] = D.arbitrary_2v(self.fval2d, self.learn_log)
+            out["electron"]["fe"] = self.sph() if self.sph is not None else D.arbitrary_2v(self.fval2d, self.learn_log)
             out["electron"]["v"] = D.velocity_grid(nvx)
         return out
 
