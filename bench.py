@@ -128,12 +128,16 @@ def main():
     ap.add_argument("--dlm", action="store_true",
                     help="variant: the reference's canonical active set {Te, ne, m, amp1, amp2, lam} with a per-lineout "
                          "super-Gaussian order m ~ U(2, 3.5) (per-lineout W tables; not the headline metric)")
+    ap.add_argument("--free-form", action="store_true",
+                    help="variant: explicit per-lineout f_e tables with the gradient w.r.t. f_e itself (Arbitrary1V-style "
+                         "free-form distribution, nvx more unknowns per lineout; not the headline metric)")
     args = ap.parse_args()
+    variant = args.dlm or args.free_form
 
     from tsadar_amd import synthetic as S
 
     cpu_res = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_sample > 0 and not args.forward_only and not args.dlm:
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_sample > 0 and not args.forward_only and not variant:
         cpu_res = cpu_baseline(S.baseline_deck(points_per_pixel=args.ppp, batch_size=args.batch), args.batch, args.cpu_sample)
 
     import torch
@@ -156,14 +160,22 @@ def main():
 
     sa = sa_lookup("P9")
     sa = dict(sa=sa["sa"], weights=sa["weights"] * np.ones([B, 10]))  # lineouts.py:103
-    eng = Engine(cfg, sa, activate=True)
+    from tsadar_amd import _lib as L
+
+    eng = Engine(cfg, sa, activate=True, fe_mode=L.FE_PER_LINEOUT if args.free_form else None)
 
     # synthetic inputs: each rank draws its own shard (seed offset by rank), data generated on the GPU
     rng = np.random.default_rng(S.SEED + rank)
     truth = S.draw_params(cfg, B, rng, dlm=args.dlm)
-    batch = S.make_batch(eng, truth, rng)
+    batch = None if args.free_form else S.make_batch(eng, truth, rng)
     guess = S.draw_params(cfg, B, rng, dlm=args.dlm)
     X = eng.dev(guess.to_matrix())
+    fe_dev = None
+    if args.free_form:  # super-Gaussians of random order as the current iterate of a free-form fit
+        from tsadar_amd import distribution as Dist
+
+        fe_dev = eng.dev(np.stack([Dist.dlm(m, eng.nvx) for m in rng.uniform(2.0, 3.5, B)]))
+        batch = S.make_batch(eng, truth, rng, fe=fe_dev)
     gmask = guess.grad_mask()
     act = torch.tensor([s for _, s in guess.slots.active_leaves], device=dev)
     P = int(act.numel())
@@ -178,8 +190,12 @@ def main():
     def step():
         if args.forward_only:
             return eng.forward(X, batch["e_amps"], batch["i_amps"])
-        eng.loss_grad(X, batch, w, gmask, out=(terms, grad))
-        g = grad[:, act].t().contiguous()
+        if args.free_form:
+            gfe = eng.loss_grad(X, batch, w, gmask, fe=fe_dev, out=(terms, grad), want_fe_grad=True)[4]
+            g = torch.cat([grad[:, act].t(), gfe.t()]).contiguous()
+        else:
+            eng.loss_grad(X, batch, w, gmask, out=(terms, grad))
+            g = grad[:, act].t().contiguous()
         return D.allreduce_loss_grad(terms, g, world, rank)
 
     def fence():
@@ -206,7 +222,7 @@ def main():
 
     # PCIe-inclusive variant (what a host L-BFGS step pays): params H2D + loss/grad D2H every step
     pcie_value = None
-    if world == 1 and not args.forward_only:
+    if world == 1 and not args.forward_only and not args.free_form:
         Xh = guess.to_matrix()
         eng.enable_timing(0)
         torch.cuda.synchronize()
@@ -229,7 +245,7 @@ def main():
     # profiles/r01_traffic.json, produced by scripts/profile_round.sh on the same workload
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tfile) and not args.forward_only and not args.dlm:
+    if os.path.exists(tfile) and not args.forward_only and not variant:
         tj = json.load(open(tfile))
         if tj.get("B") == B and tj.get("ppp") == args.ppp:
             traffic = tj["hbm_bytes_per_launch"]
@@ -237,7 +253,7 @@ def main():
     achieved = B * abytes / kavg_s / 1e9
     res = {
         "metric": ("spectra/sec (fwd+grad), 1024-lambda EPW+IAW form factor, batch 4096" if not args.forward_only
-                   else "spectra/sec (forward only), 1024-lambda EPW+IAW form factor") + (" [DLM variant: per-lineout f_e]" if args.dlm else ""),
+                   else "spectra/sec (forward only), 1024-lambda EPW+IAW form factor") + (" [DLM variant: per-lineout f_e]" if args.dlm else "") + (" [free-form f_e variant: + gradient w.r.t. f_e]" if args.free_form else ""),
         "value": value,
         "unit": "spectra/s",
         "n_gpus": world,
@@ -251,7 +267,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (("configs[2]: batch 4096 EPW+IAW spectra forward+adjoint (loss+grad as inside the L-BFGS fit loop), "
-                          "6 free params {Te, ne, Ti, Va, lam, amp1}, Maxwellian f_e (shared W table)") if not args.dlm else
+                          "6 free params {Te, ne, Ti, Va, lam, amp1}, Maxwellian f_e (shared W table)") if not variant else
+                         ("configs[2] variant: batch 4096 EPW+IAW spectra forward+adjoint, 6 free params + the 128 values of a free-form "
+                          "per-lineout f_e (table adjoints, transposed MFMA GEMM, generator chain rule left to the host)") if args.free_form else
                          ("configs[2] variant: batch 4096 EPW+IAW spectra forward+adjoint, 6 free params {Te, ne, m, amp1, amp2, lam} "
                           "of the reference's 1-D fit test, per-lineout DLM f_e (W and dW/dm tables rebuilt every step)"))
             if not args.forward_only else "configs[1]-like: forward-only EPW+IAW spectra, Maxwellian f_e",

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TSFF_ABI_VERSION 3
+#define TSFF_ABI_VERSION 4
 
 /* ---- parameter slots of one lineout: params[b][TSFF_NP(n_ion)] (normalised leaves of the
  * reference's ThomsonParams pytree, core/modules/ts_params.py:49-60,395-420,253-262) ---------- */
@@ -214,6 +214,17 @@ int tsff_loss_grad(tsff_handle *h, const double *params, const double *fe, const
                    const double *noise_e, const double *noise_i, int32_t B,
                    const double *weights, const uint8_t *grad_mask, double *loss_terms,
                    double *grad, double *ThryE, double *ThryI);
+
+/* The same plus the gradient w.r.t. the tabulated distribution function itself: grad_fe [B][nvx] (device) =
+ * d loss / d fe[b][i], for fe_mode == TSFF_FE_PER_LINEOUT.  This is what equinox.filter_value_and_grad returns for the
+ * leaves of a free-form distribution (Arbitrary1V.fval, core/modules/distribution_functions/base.py:157-204, filter
+ * spec :462-471) before the generator's own chain rule, which stays on the host.  The adjoint runs through both uses of
+ * f_e: the Hermite interpolant of ln f_e at the phase velocity (form_factor.py:256) and the Re(chi_e) table
+ * (form_factor.py:263-268, ratintn.py) via one transposed GEMM with the constant log-ratio table. */
+int tsff_loss_grad_fe(tsff_handle *h, const double *params, const double *fe, const double *e_data, const double *i_data,
+                      const double *e_amps, const double *i_amps, const double *noise_e, const double *noise_i, int32_t B,
+                      const double *weights, const uint8_t *grad_mask, double *loss_terms, double *grad, double *grad_fe,
+                      double *ThryE, double *ThryI);
 
 /* LossFunction.array_loss: per-lineout masked sums with the theory spectrum as denominator
  * ((d-t)^2/t, loss_function.py:320-321).  sums [B][3] = S_iaw, S_blue, S_red per lineout;

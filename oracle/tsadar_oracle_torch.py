@@ -348,3 +348,16 @@ def value_and_grad(cfg, sa, normed_np, batch, i_norm, e_norm, names, activate=Tr
     grads = torch.autograd.grad(val, [normed[k] for k in names], allow_unused=True)
     out = {k: (g.numpy() if g is not None else np.zeros_like(normed_np[k])) for k, g in zip(names, grads)}
     return float(val.detach()), out, E.detach().numpy(), I.detach().numpy()
+
+
+def value_and_grad_fe(cfg, sa, normed_np, batch, i_norm, e_norm, names, fe_batch, activate=True):
+    """As value_and_grad plus d loss / d fe_batch [B, nvx]: what equinox.filter_value_and_grad yields for the
+    leaves of a free-form distribution function before the generator's own chain rule (base.py:157-204)."""
+    normed = {k: _t(v).clone() for k, v in normed_np.items()}
+    for k in names:
+        normed[k].requires_grad_(True)
+    fe = _t(np.asarray(fe_batch)).clone().requires_grad_(True)
+    val, E, I = loss(cfg, sa, normed, batch, i_norm, e_norm, activate, fe)
+    grads = torch.autograd.grad(val, [normed[k] for k in names] + [fe], allow_unused=True)
+    out = {k: (g.numpy() if g is not None else np.zeros_like(normed_np[k])) for k, g in zip(names, grads[:-1])}
+    return float(val.detach()), out, grads[-1].numpy(), E.detach().numpy(), I.detach().numpy()

@@ -679,3 +679,101 @@ def test_angular_diagnostic_end_to_end(torch_mod, dim, fe_type):
         p = orc.lineout_params(orc.physical_params(cfg["parameters"], orc.init_normed_params(cfg["parameters"], 1, True), True), 0, 1)
         Eo, _ = orc.ats_spectrum(cfg, sa["weights"], sa["angAxis"], P, np.linspace(400, 700, 1024), 1024, np.ones((860, 1)), p)
         assert np.max(np.abs(E - Eo)) / np.max(np.abs(Eo)) < 1e-10
+
+
+def _free_form_fe(B, nvx, seed):
+    """Free-form distribution functions: super-Gaussians modulated by a smooth asymmetric factor, renormalised."""
+    rng = np.random.default_rng(seed)
+    vx = orc.velocity_grid(nvx)
+    fes = []
+    for b in range(B):
+        f = orc.dlm_fe(rng.uniform(2.0, 3.5), nvx) * np.exp(0.15 * np.sin(1.3 * vx + rng.uniform(0, 6.28)) + 0.05 * np.tanh(vx))
+        fes.append(f / np.sum(f) / (vx[1] - vx[0]))
+    return np.stack(fes)
+
+
+@pytest.mark.parametrize("nvx", [128, 64])
+def test_gradient_wrt_distribution_function(torch_mod, nvx):
+    """SURVEY 8(f1), free-form f_e: d loss / d fe[b, i] from tsff_loss_grad_fe (table adjoints scattered in k_spectrum,
+    transposed MFMA GEMM with the log-ratio table, k_fe_adjoint) vs reverse-mode autodiff of the oracle twin through
+    both uses of f_e (Hermite ln f_e lookup and the 1640 x 1022 ratintn table), together with the plasma parameters."""
+    from oracle import tsadar_oracle_torch as ot
+
+    B = 2
+    names = ["Te", "ne", "Ti_1", "Va", "lam", "amp1"]
+    cfg = decks.deck_fit(nvx=nvx)
+    sa = util.sa_fit(B)
+    batch = util.synthetic_batch(cfg, sa, B, seed=71)
+    normed = util.random_lineouts(cfg, B, seed=73)
+    i_norm, e_norm = orc.loss_norms(cfg, batch)
+    fe = _free_form_fe(B, nvx, 5)
+    eng = _engine(cfg, sa, fe_mode=L.FE_PER_LINEOUT)
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    terms, grad, E, I, gfe = eng.loss_grad(util.normed_to_matrix(normed, 1), batch, w, eng.slots.active.astype(np.uint8),
+                                           fe=fe, want_spectra=True, want_fe_grad=True)
+    val, ref, ref_fe, Eo, Io = ot.value_and_grad_fe(cfg, sa, normed, batch, i_norm, e_norm, names, fe)
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-8 and util.rel_err(I.cpu().numpy(), Io) < 1e-8
+    assert abs(float(np.dot(terms.cpu().numpy(), w)) - val) < 1e-9 * abs(val)
+    G = util.matrix_to_named(grad.cpu().numpy(), names)
+    scale = max(np.max(np.abs(v)) for v in ref.values())
+    for k in names:
+        assert np.max(np.abs(G[k] - ref[k])) / scale < 1e-7, (k, G[k], ref[k])
+    gfe = gfe.cpu().numpy()
+    assert gfe.shape == (B, nvx) and np.all(np.isfinite(gfe))
+    # compare as d loss / d ln fe (= fe * d loss / d fe): the tails of fe span 20 decades
+    a, r = gfe * fe, ref_fe * fe
+    err = np.max(np.abs(a - r)) / np.max(np.abs(r))
+    assert err < 1e-7, err
+    # and the plain gradient where fe is not negligible
+    big = fe > 1e-6 * fe.max()
+    assert np.max(np.abs(gfe[big] - ref_fe[big])) / np.max(np.abs(ref_fe[big])) < 1e-6
+
+
+def test_vg_loss_free_form_distribution(torch_mod):
+    """LossFunction.vg_loss with an Arbitrary1V distribution function (base.py:157-204; filter spec :462-471): the flat
+    gradient carries nvx values per lineout right after (Te, ne), in the reference's ravel order, chained through the
+    generator (Butterworth smoothing, 10 ** -(7 u)^2, normalisation) on the host."""
+    from oracle import tsadar_oracle_torch as ot
+    from tsadar_amd import ThomsonParams, tree
+    from tsadar_amd import distribution as D
+    from tsadar_amd.loss_function import LossFunction
+
+    B, nvx = 2, 64
+    cfg = decks.deck_fit(nvx=nvx, active=("Te", "ne", "amp1", "lam"))
+    cfg["parameters"]["electron"]["fe"] = {"active": True, "type": "arbitrary", "dim": 1, "nvx": nvx, "params": {"init_m": 2.4}}
+    sa = util.sa_fit(B)
+    cfg_data = decks.deck_fit(nvx=nvx)
+    batch = util.synthetic_batch(cfg_data, sa, B, seed=81)
+    loss_fn = LossFunction(cfg, sa, batch)
+    tp = ThomsonParams(cfg["parameters"], B, batch=True, activate=True)
+    rng = np.random.default_rng(4)
+    tp.fval = tp.fval * (1 + 0.02 * rng.normal(size=tp.fval.shape))
+    tp.X[:, L.P_TE] += rng.normal(size=B) * 0.1
+    spec = tree.get_filter_spec(cfg["parameters"], tp)
+    assert [n for n, _ in spec] == [("electron", "Te"), ("electron", "ne"), ("electron", "fval"), ("general", "lam"), ("general", "amp1")]
+    diff, static = tree.partition(tp, spec)
+    x0, loss_fn.unravel_weights = tree.ravel_pytree(diff)
+    assert x0.size == 4 * B + B * nvx
+    val, g = loss_fn.vg_loss(x0, static, batch)
+    # oracle: autodiff w.r.t. (Te, ne, lam, amp1) and f_e, then the generator's chain rule
+    fe = D.arbitrary_1v(tp.fval)
+    names = ["Te", "ne", "lam", "amp1"]
+    cfg_o = decks.deck_fit(nvx=nvx, active=("Te", "ne", "amp1", "lam"))  # same activation flags, explicit f_e
+    normed = {k: tp.X[:, util.slot_of(k)].copy() for k in orc.init_normed_params(cfg_o["parameters"], B, True)}
+    i_norm, e_norm = orc.loss_norms(cfg, batch)
+    vo, ref, ref_fe, _, _ = ot.value_and_grad_fe(cfg_o, sa, normed, batch, i_norm, e_norm, names, fe)
+    assert abs(val - vo) < 1e-9 * abs(vo)
+    expect = np.concatenate([ref["Te"], ref["ne"], D.arbitrary_1v_vjp(tp.fval, ref_fe).ravel(), ref["lam"], ref["amp1"]])
+    assert np.max(np.abs(g - expect)) / np.max(np.abs(expect)) < 1e-7
+    # self-consistency: directional derivative of vg_loss's own value
+    d = rng.normal(size=x0.size)
+    d /= np.linalg.norm(d)
+    h = 1e-6
+    vp, _ = loss_fn.vg_loss(x0 + h * d, static, batch)
+    vm, _ = loss_fn.vg_loss(x0 - h * d, static, batch)
+    assert abs((vp - vm) / (2 * h) - np.dot(g, d)) < 1e-5 * np.linalg.norm(g)
+    # one L-BFGS-B iteration lowers the loss
+    import scipy.optimize as so
+
+    res = so.minimize(loss_fn.vg_loss, x0, args=(static, batch), method="L-BFGS-B", jac=True, options={"maxiter": 3})
+    assert res.fun < val

@@ -186,3 +186,38 @@ def test_spherical_harmonics_generator():
     cfg["parameters"]["electron"]["fe"] = dc
     tp = ThomsonParams(cfg["parameters"], 1, batch=False, activate=True)
     np.testing.assert_allclose(tp()["electron"]["fe"], f, rtol=0, atol=0)
+
+
+def test_arbitrary_1v_generator_and_ravel_order():
+    """Arbitrary1V host mirror: Butterworth smoothing as a matrix == the scan, normalisation, VJP vs finite
+    differences, and the position of the fval leaves in the flat vector."""
+    nvx = 48
+    fv = D.arbitrary_1v_init(2.5, nvx) * (1 + 0.05 * np.sin(np.arange(nvx)))
+    S = D.butterworth_matrix(nvx)
+    fwd = D._butterworth_pass(fv, 100.0, 6.0)
+    ref = D._butterworth_pass(fwd[::-1], 100.0, 6.0)[::-1]
+    np.testing.assert_allclose(S @ fv, ref, rtol=1e-12, atol=1e-14)
+    fe = D.arbitrary_1v(fv)
+    assert abs(np.sum(fe) * 12.0 / nvx - 1) < 1e-13 and np.all(fe > 0)
+    g = np.random.default_rng(1).normal(size=nvx)
+    v = D.arbitrary_1v_vjp(fv, g)
+    for i in (0, 7, 24, 47):
+        a, b = fv.copy(), fv.copy()
+        a[i] += 1e-6
+        b[i] -= 1e-6
+        fd = (np.dot(g, D.arbitrary_1v(a)) - np.dot(g, D.arbitrary_1v(b))) / 2e-6
+        assert abs(fd - v[i]) < 1e-6 * max(1.0, abs(v[i]))
+    cfg = decks.deck_fit(nvx=nvx, active=("Te", "Ti", "lam"))
+    cfg["parameters"]["electron"]["fe"] = {"active": True, "type": "arbitrary", "dim": 1, "nvx": nvx, "params": {"init_m": 3.0}}
+    tp = ThomsonParams(cfg["parameters"], 3, batch=True, activate=True)
+    assert tp.fval.shape == (3, nvx) and tp()["electron"]["fe"].shape == (3, nvx)
+    spec = tree.get_filter_spec(cfg["parameters"], tp)
+    assert [n for n, _ in spec] == [("electron", "Te"), ("electron", "fval"), ("ion-1", "Ti"), ("general", "lam")]
+    diff, static = tree.partition(tp, spec)
+    flat, unravel = tree.ravel_pytree(diff)
+    assert flat.size == 3 * 3 + 3 * nvx
+    np.testing.assert_array_equal(flat[3 : 3 + nvx], tp.fval[0])       # lineout-major fval leaves
+    back = tree.combine(static, unravel(flat * 1.0))
+    np.testing.assert_array_equal(back.fval, tp.fval)
+    fitted, n = tp.get_fitted_params(cfg["parameters"])
+    assert "f" in fitted["electron"] and n == 4

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsff.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_ION = 4
 NBINS = 1024
 NXI1 = 1024
@@ -111,6 +111,7 @@ _SIGNATURES = {
     "tsff_ats_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "tsff_forward": (C.c_int, [_vp] + [_vp] * 6 + [C.c_int32, _vp, _vp]),
     "tsff_loss_grad": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, _vp, _vp, _vp, _vp]),
+    "tsff_loss_grad_fe": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, _vp, _vp, _vp, _vp, _vp]),
     "tsff_array_loss": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "tsff_enable_timing": (C.c_int, [_vp, C.c_int32]),
     "tsff_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),

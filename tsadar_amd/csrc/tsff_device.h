@@ -119,9 +119,58 @@ struct Tables {
   const double2* hc;   // [2*(nvx-1)] cubic coefficients per interval: (f0, m0), (c2, c3)   (spectrum kernels)
   const double2* hcm;  // the same for d(ln fe)/dm (gradient w.r.t. the DLM order), or nullptr
   const double* Wm;    // [1640] dW/dm, or nullptr
+  double* Wb;          // [1640] adjoint of W            (gradient w.r.t. the distribution function itself, GM == 2)
+  double* Hy;          // [nvx]  adjoint of the ln fe node values
+  double* Hs;          // [nvx]  adjoint of the ln fe node slopes
   double vx0, dv, idv, vxlast;
   int nvx;
 };
+
+// Gradient w.r.t. the tabulated distribution function (GM == 2): every point scatters the adjoint of its two table
+// lookups into the table adjoints in LDS.  Neighbouring points of one thread fall into the same table interval most of
+// the time, so a thread keeps run-length accumulators and only issues LDS atomics when its interval changes.
+struct FeAcc {
+  int iw, ih;
+  double w0, w1, y0, y1, s0, s1;
+};
+__device__ __forceinline__ void fe_acc_init(FeAcc& a) { a.iw = a.ih = -1; a.w0 = a.w1 = a.y0 = a.y1 = a.s0 = a.s1 = 0.0; }
+__device__ __forceinline__ void fe_flush_w(FeAcc& a, double* Wb) {
+  if (a.iw >= 0) { atomicAdd(&Wb[a.iw], a.w0); atomicAdd(&Wb[a.iw + 1], a.w1); }
+  a.w0 = a.w1 = 0.0;
+}
+__device__ __forceinline__ void fe_flush_h(FeAcc& a, double* Hy, double* Hs) {
+  if (a.ih >= 0) {
+    atomicAdd(&Hy[a.ih], a.y0); atomicAdd(&Hy[a.ih + 1], a.y1);
+    atomicAdd(&Hs[a.ih], a.s0); atomicAdd(&Hs[a.ih + 1], a.s1);
+  }
+  a.y0 = a.y1 = a.s0 = a.s1 = 0.0;
+}
+// adjoint of w_lookup w.r.t. the table: wb = adjoint of the interpolated value
+__device__ __forceinline__ void fe_add_w(FeAcc& a, double* Wb, double xe, double wb) {
+  const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
+  const double u = (xe - kXi2_0) * kXi2_ih;
+  int i = (int)u;
+  i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
+  double t = (xe - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
+  t = xe < kXi2_0 ? 0.0 : (xe > xlast ? 1.0 : t);  // clamped lookups read an end node
+  if (i != a.iw) { fe_flush_w(a, Wb); a.iw = i; }
+  a.w0 += wb * (1.0 - t);
+  a.w1 += wb * t;
+}
+// adjoint of hermite_lookup w.r.t. the node values and slopes: hb = adjoint of H = ln f_e(x)
+__device__ __forceinline__ void fe_add_h(FeAcc& a, const Tables& T, double x, double hb) {
+  if (x < T.vx0 || x > T.vxlast) return;  // constant -50 outside the grid
+  const double u = (x - T.vx0) * T.idv;
+  int i = (int)u;
+  i = i < 0 ? 0 : (i > T.nvx - 2 ? T.nvx - 2 : i);
+  const double t = (x - (T.vx0 + i * T.dv)) * T.idv;
+  if (i != a.ih) { fe_flush_h(a, T.Hy, T.Hs); a.ih = i; }
+  const double t2 = t * t, t3 = t2 * t;
+  a.y0 += hb * (2.0 * t3 - 3.0 * t2 + 1.0);
+  a.y1 += hb * (3.0 * t2 - 2.0 * t3);
+  a.s0 += hb * (t3 - 2.0 * t2 + t) * T.dv;
+  a.s1 += hb * (t3 - t2) * T.dv;
+}
 
 // jnp.interp(xie, xi2, W): clamps to the end values outside the table (form_factor.py:270)
 __device__ __forceinline__ void w_lookup(const double* W, double xe, double& w, double& dw) {
@@ -435,10 +484,11 @@ struct BaseAdj {  // adjoints flowing into base quantities of a point
 
 // reverse of point_forward: given Pbar, produce adjoints of this point's base quantities (ba),
 // of the right neighbour's (xe, F) (xen, Fn), and accumulate lineout-scalar adjoints into LB.
-template <int NI, bool WM = false>
+// GM: 0 plasma parameters only, 1 + DLM order m (tangent tables), 2 + the distribution-function tables themselves
+template <int NI, int GM = 0>
 __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Base& bn, bool has_next,
                                               const LineS<NI>& L, const Tables& T, double Pbar,
-                                              BaseAdj& ba, double& xen, double& Fn, LineS<NI>& LB) {
+                                              BaseAdj& ba, double& xen, double& Fn, LineS<NI>& LB, FeAcc& fa) {
   // ---- recompute forward ----
   const double ik2 = b.ik * b.ik;
   const double ike2 = L.a_e * ik2;
@@ -486,11 +536,12 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
   double ike2b = -cerb * Wl + ceib * kPi * D;
   const double Wlb = -cerb * ike2;  // adjoint of the interpolated W
   ba.xe = Wlb * dW;
-  if (WM) {  // W depends on the DLM order through the table itself
+  if (GM == 1) {  // W depends on the DLM order through the table itself
     double Wml, dWm;
     w_lookup(T.Wm, b.xe, Wml, dWm);
     LB.m += Wlb * Wml;
   }
+  if (GM == 2) fe_add_w(fa, T.Wb, b.xe, Wlb);
   const double Db = ceib * kPi * ike2;
   // D = (Fn - F) * idx
   Fn = Db * idx;
@@ -518,11 +569,12 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
 }
 
 // reverse of base_eval
-template <int NI, bool WM = false>
+template <int NI, int GM = 0>
 __device__ __forceinline__ void base_reverse(double ct, const Base& b, const LineS<NI>& L, const Tables& T,
-                                             const BaseAdj& ba, LineS<NI>& LB) {
+                                             const BaseAdj& ba, LineS<NI>& LB, FeAcc& fa) {
   const double Hb = ba.F * b.F;  // adjoint of H = ln f_e(xi_e)
-  if (WM) {  // d ln f_e(xi_e)/dm: Hermite interpolant of the tangent table (zero outside the vx grid)
+  if (GM == 2) fe_add_h(fa, T, b.xe, Hb);
+  if (GM == 1) {  // d ln f_e(xi_e)/dm: Hermite interpolant of the tangent table (zero outside the vx grid)
     Tables Tm = T;
     Tm.hc = T.hcm;
     double Hm, dHm;

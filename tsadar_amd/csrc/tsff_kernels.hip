@@ -50,6 +50,9 @@ struct KCall {
   const double* W;       // [slots][1640]
   const double2* htm;    // [slots][nvx]  d(ln fe, slope)/dm   (WITH_M)
   const double* Wm;      // [slots][1640] dW/dm                (WITH_M)
+  double* Wb_out;        // [B][1640] adjoint of the W table       (gradient w.r.t. f_e, GM == 2)
+  double* Hy_out;        // [B][nvx]  adjoint of the ln fe node values
+  double* Hs_out;        // [B][nvx]  adjoint of the ln fe node slopes
   const double* amps[2];
   const double* noise[2];
   const double* data[2];
@@ -298,6 +301,9 @@ __global__ __launch_bounds__(kThreads) void k_fe_vectors(KStatic S, const double
 // lineout and 16 consecutive q sit on 16 consecutive lanes, so the epilogue needs no shuffle and writes 128-B runs.
 constexpr int kGM = 128, kGN = 128, kGK = 16, kGP = 132;  // kGP: LDS row pitch in doubles
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+// NC = 4: (A, s, dA/dm, ds/dm), 4 lineouts per 16-row tile.  NC = 2: no tangents (explicit f_e tables), 8 lineouts per
+// tile, rows (component, lineout): a lane then holds (A, A', s, s') of lineouts fk and fk + 4.
+template <int NC>
 __global__ __launch_bounds__(kThreads, 2) void k_wgemm(const double* __restrict__ Lg, const double* __restrict__ X,
                                                     const double* __restrict__ cst, const double* __restrict__ xi2,
                                                     int B, double* __restrict__ W, double* __restrict__ Wm) {
@@ -309,12 +315,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_wgemm(const double* __restrict_
   constexpr int nQ = (kNXi2 + kGN - 1) / kGN;
   const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
   const int mtile = xcd + 8 * (jx / nQ), qtile = jx % nQ;
-  if (mtile * (kGM / 4) >= B) return;
-  const int q0 = qtile * kGN, b0 = mtile * (kGM / 4);
+  constexpr int LPT = 16 / NC;  // lineouts per 16-row MFMA tile
+  if (mtile * (kGM / NC) >= B) return;
+  const int q0 = qtile * kGN, b0 = mtile * (kGM / NC);
   // staging: thread -> LDS row lr, kGK/2 consecutive k starting at lk
   const int lr = tid >> 1, lk = (tid & 1) * (kGK / 2);
   constexpr int kPF = kGK / 4;  // double2 loads per thread and operand
-  const int sb = b0 + (lr >> 4) * 4 + (lr & 3), sc = (lr >> 2) & 3;  // lineout / component of X row lr
+  const int sb = b0 + (lr >> 4) * LPT + (lr & (LPT - 1)), sc = (lr & 15) / LPT;  // lineout / component of X row lr
   const double* __restrict__ xrow = X + ((size_t)min(sb, B - 1) * 4 + sc) * kNXi1 + lk;
   const double* __restrict__ lrow = Lg + (size_t)min(q0 + lr, kNXi2 - 1) * kNXi1 + lk;
   mfma_d4 acc[4][4];
@@ -369,18 +376,188 @@ __global__ __launch_bounds__(kThreads, 2) void k_wgemm(const double* __restrict_
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int bb = b0 + (wm * 4 + i) * 4 + fk;
-    if (bb >= B) continue;
-    const double c0 = cst[2 * bb], c1 = cst[2 * bb + 1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = q0 + wn * 64 + j * 16 + fr;
-      if (q < kNXi2) {
-        const double x2 = xi2[q];
-        W[(size_t)bb * kNXi2 + q] = c0 + acc[i][j][0] + x2 * acc[i][j][1];
-        Wm[(size_t)bb * kNXi2 + q] = c1 + acc[i][j][2] + x2 * acc[i][j][3];
+    for (int u = 0; u < (NC == 4 ? 1 : 2); ++u) {
+      const int bb = b0 + (wm * 4 + i) * LPT + fk + 4 * u;
+      if (bb >= B) continue;
+      const double c0 = cst[2 * bb], c1 = cst[2 * bb + 1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = q0 + wn * 64 + j * 16 + fr;
+        if (q < kNXi2) {
+          const double x2 = xi2[q];
+          if (NC == 4) {
+            W[(size_t)bb * kNXi2 + q] = c0 + acc[i][j][0] + x2 * acc[i][j][1];
+            Wm[(size_t)bb * kNXi2 + q] = c1 + acc[i][j][2] + x2 * acc[i][j][3];
+          } else {
+            W[(size_t)bb * kNXi2 + q] = c0 + acc[i][j][u] + x2 * acc[i][j][2 + u];
+          }
+        }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Gradient w.r.t. the distribution function itself (fe_mode PER_LINEOUT, SURVEY 8f-1 "free-form f_e").
+// k_spectrum<.., GM = 2> leaves per lineout the adjoints of its tables: Wb[1640] (Re chi_e table) and Hy/Hs[nvx]
+// (ln fe node values / slopes).  The W table is W = c0 + Lg (A + xi2 s), so its adjoint is the transposed GEMM
+//   Y[b][0][i] = sum_q Wb[b][q] Lg[q][i]            (adjoint of A)
+//   Y[b][1][i] = sum_q xi2[q] Wb[b][q] Lg[q][i]     (adjoint of s)
+// done by k_wgemm_t on the FP64 matrix cores (M = 2B vectors, N = 1024, K = 1640), and k_fe_adjoint walks
+// k_fe_vectors backwards (X construction, central differences, exp, Hermite evaluation at xi1, node slopes, ln).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads, 2) void k_wgemm_t(const double* __restrict__ Lg, const double* __restrict__ Wb,
+                                                         const double* __restrict__ xi2, int B, double* __restrict__ Y) {
+  __shared__ double Vs[kGK][kGP];   // [k][vector]
+  __shared__ double Ls[kGK][kGP];   // [k][i]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int v0 = blockIdx.y * kGM, i0 = blockIdx.x * kGN;
+  // staging of V: thread -> vector row lr, 8 consecutive q starting at lk; of Lg: row (q) sk, 8 consecutive i at sn
+  const int lr = tid >> 1, lk = (tid & 1) * 8;
+  const int vb = (v0 + lr) >> 1, vc = (v0 + lr) & 1;
+  const double* __restrict__ vrow = Wb + (size_t)min(vb, B - 1) * kNXi2 + lk;
+  const int sk = tid >> 4, sn = (tid & 15) * 8;
+  const double* __restrict__ lrow = Lg + (size_t)sk * kNXi1 + i0 + sn;
+  mfma_d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int k0 = 0; k0 < kNXi2; k0 += kGK) {
+    double pv[8];
+    double2 pl[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int q = k0 + lk + j;
+      const double w = q < kNXi2 ? vrow[k0 + j] : 0.0;
+      pv[j] = vc ? w * (q < kNXi2 ? xi2[q] : 0.0) : w;
+    }
+    const bool lok = k0 + sk < kNXi2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      pl[j] = lok ? *reinterpret_cast<const double2*>(lrow + (size_t)k0 * kNXi1 + 2 * j) : make_double2(0.0, 0.0);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Vs[lk + j][lr] = pv[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<double2*>(&Ls[sk][sn + 2 * j]) = pl[j];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < kGK; ks += 4) {
+      double a[4], c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = Vs[ks + fk][wm * 64 + i * 16 + fr];
+        c[i] = Ls[ks + fk][wn * 64 + i * 16 + fr];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], c[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // C/D layout: col = lane & 15 (i), row = (lane >> 4) + 4 reg (vector inside the 16-row tile)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int v = v0 + wm * 64 + i * 16 + fk + 4 * r;
+      if (v >= 2 * B) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Y[(size_t)v * kNXi1 + i0 + wn * 64 + j * 16 + fr] = acc[i][j][r];
+    }
+}
+
+// k_fe_adjoint: grid B, 256 threads.  In: ht [B][nvx] (ln fe, slope) of the forward pass, Y [B][2][1024], Wb [B][1640]
+// (for the adjoint of c0 = sum_q Wb), Hy/Hs [B][nvx] from k_spectrum.  Out: dfe [B][nvx] = d loss / d f_e.
+__global__ __launch_bounds__(kThreads) void k_fe_adjoint(KStatic S, const double2* __restrict__ ht_in,
+                                                         const double* __restrict__ Y, const double* __restrict__ Wb,
+                                                         const double* __restrict__ Hy_in, const double* __restrict__ Hs_in,
+                                                         double* __restrict__ dfe) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* ht = reinterpret_cast<double2*>(smem);   // [nvx]
+  double2* hc = ht + S.nvx;                         // [2 nvx]
+  double* rat = reinterpret_cast<double*>(hc + 2 * S.nvx);  // [1024]
+  double* fdb = rat + kNXi1;                        // [1024] adjoint of fdif, later of rat
+  double* fab = fdb + kNXi1;                        // [1024] adjoint of fav
+  double* rdb = fab + kNXi1;                        // [1024] adjoint of ratdf
+  double* yb = rdb + kNXi1;                         // [nvx]
+  double* sb = yb + S.nvx;                          // [nvx]
+  double* red = sb + S.nvx;                         // [8]
+  const int b = blockIdx.x, tid = threadIdx.x, nvx = S.nvx;
+  for (int i = tid; i < nvx; i += kThreads) {
+    ht[i] = ht_in[(size_t)b * nvx + i];
+    yb[i] = Hy_in[(size_t)b * nvx + i];
+    sb[i] = Hs_in[(size_t)b * nvx + i];
+  }
+  double part = 0.0;
+  for (int q = tid; q < kNXi2; q += kThreads) part += Wb[(size_t)b * kNXi2 + q];
+  const double c0b = block_sum(part, red);  // (contains the barrier that publishes ht)
+  for (int i = tid; i < nvx - 1; i += kThreads) hermite_coeffs(ht[i], ht[i + 1], S.dv, hc[2 * i], hc[2 * i + 1]);
+  __syncthreads();
+  Tables T;
+  T.zp = nullptr; T.W = nullptr; T.ht = ht; T.hc = hc; T.hcm = nullptr; T.Wm = nullptr; T.nvx = nvx;
+  T.Wb = nullptr; T.Hy = yb; T.Hs = sb;
+  T.vx0 = S.vx0; T.dv = S.dv; T.idv = 1.0 / S.dv; T.vxlast = S.vx0 + (nvx - 1) * S.dv;
+  const double* Ab = Y + (size_t)b * 2 * kNXi1;
+  const double* Sb = Ab + kNXi1;
+  for (int i = tid; i < kNXi1; i += kThreads) {
+    double H, dH;
+    hermite_lookup_c(T, S.xi1[i], H, dH);
+    rat[i] = exp(H);
+    // X construction (k_fe_vectors): Bs = fd ih, A = fa - mid Bs, c0 += fd   for i < 1022
+    double fd = 0.0, fa = 0.0;
+    if (i < kNXi1 - 2) {
+      const double x0 = S.xi1[i], x1 = S.xi1[i + 1];
+      const double ih = 1.0 / (x1 - x0), mid = 0.5 * (x1 + x0);
+      fa = Ab[i];
+      fd = (Sb[i] - mid * fa) * ih + c0b;
+    }
+    fdb[i] = fd;
+    fab[i] = fa;
+  }
+  __syncthreads();
+  // fd_i = rdf[i+1] - rdf[i], fa_i = (rdf[i+1] + rdf[i]) / 2
+  for (int j = tid; j < kNXi1; j += kThreads) {
+    double v = 0.0;
+    if (j < kNXi1 - 2) v += -fdb[j] + 0.5 * fab[j];
+    if (j >= 1 && j <= kNXi1 - 2) v += fdb[j - 1] + 0.5 * fab[j - 1];
+    rdb[j] = v;
+  }
+  __syncthreads();
+  // rdf = gradient(rat, h1): central inside, one-sided at the ends
+  const double ih1 = 1.0 / (S.xi1[1] - S.xi1[0]);
+  const int n = kNXi1;
+  for (int j = tid; j < n; j += kThreads) {
+    double v = 0.0;
+    if (j + 1 >= 1 && j + 1 <= n - 2) v -= 0.5 * ih1 * rdb[j + 1];
+    if (j - 1 >= 1 && j - 1 <= n - 2) v += 0.5 * ih1 * rdb[j - 1];
+    if (j == 1) v += ih1 * rdb[0];
+    if (j == 0) v -= ih1 * rdb[0];
+    if (j == n - 1) v += ih1 * rdb[n - 1];
+    if (j == n - 2) v -= ih1 * rdb[n - 1];
+    fdb[j] = v * rat[j];  // adjoint of H(xi1_j)  (rat = exp H)
+  }
+  __syncthreads();
+  {  // scatter to the nodes: each thread walks consecutive xi1 points, so the run-length accumulators rarely flush
+    FeAcc fa;
+    fe_acc_init(fa);
+    const int per = (kNXi1 + kThreads - 1) / kThreads;
+    for (int j = tid * per; j < min((tid + 1) * per, kNXi1); ++j) fe_add_h(fa, T, S.xi1[j], fdb[j]);
+    fe_flush_h(fa, yb, sb);
+  }
+  __syncthreads();
+  // node slopes: mean of the adjacent secants, one-sided at the ends (k_fe_vectors)
+  for (int j = tid; j < nvx; j += kThreads) {
+    double v = yb[j];
+    const double idv = 1.0 / S.dv;
+    if (j >= 1) v += sb[j - 1] * (j - 1 == 0 ? idv : 0.5 * idv);        // s_{j-1} reads y_j with +
+    if (j + 1 <= nvx - 1) v -= sb[j + 1] * (j + 1 == nvx - 1 ? idv : 0.5 * idv);  // s_{j+1} reads y_j with -
+    if (j == 0) v -= sb[0] * idv;
+    if (j == nvx - 1) v += sb[nvx - 1] * idv;
+    dfe[(size_t)b * nvx + j] = v * exp(-ht[j].x);  // y = ln fe
   }
 }
 
@@ -478,6 +655,7 @@ __device__ __forceinline__ void load_tables(const Smem& m, const KStatic& S, con
   }
   for (int i = tid; i < S.n_angles; i += nthr) { m.cosa[i] = S.cos_sa[i]; m.wsa[i] = S.w_sa[i]; }
   T.zp = m.zp; T.W = m.W; T.ht = m.ht; T.hc = m.hc; T.hcm = m.hcm; T.Wm = m.Wm; T.nvx = S.nvx;
+  T.Wb = nullptr; T.Hy = nullptr; T.Hs = nullptr;
   T.vx0 = S.vx0; T.dv = S.dv; T.idv = 1.0 / S.dv; T.vxlast = S.vx0 + (S.nvx - 1) * S.dv;
 }
 
@@ -559,7 +737,7 @@ __device__ __forceinline__ void loss_point(int method, double d, double t, doubl
 //   MODE 1: + masked loss sums + adjoint -> grad      (LossFunction.vg_loss)
 //   MODE 2: + per-lineout sums, theory denominator, sqdev arrays (LossFunction.array_loss)
 // ------------------------------------------------------------------------------------------
-template <int NI, int MODE, bool WM = false, int TPF = kHalf>
+template <int NI, int MODE, int GM = 0, int TPF = kHalf>
 __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCall K, int f0, int nfeat, int flags,
                                                            const uint8_t* __restrict__ gmask, double* __restrict__ grad) {
   // flags bit 0: add to grad instead of overwriting it (second launch of a feature-split call);
@@ -572,7 +750,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   const int half = tid / TPF, ht = tid % TPF, lane = tid & 63, hw = ht >> 6;
   const int f = f0 + half;  // feature of this group (wavefront-uniform)
   extern __shared__ __align__(16) unsigned char smem[];
-  const Smem m = carve(smem, S, nfeat, WM, use_ks);
+  const Smem m = carve(smem, S, nfeat, GM != 0, use_ks);
   Tables T;
   load_tables(m, S, K, S.shared_fe ? 0 : b, true, T);
 
@@ -778,6 +956,14 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   double* gsum = m.red + 8 * kNP_MAX;           // [2][NPk] physical-parameter adjoints of the two features
   if (ht < NPk) gsum[half * NPk + ht] = 0.0;
   const int wv = tid >> 6;
+  FeAcc fa;
+  fe_acc_init(fa);
+  if (GM == 2) {  // table adjoints live where the tangent tables of GM == 1 would (same LDS budget)
+    T.Wb = m.Wm; T.Hy = reinterpret_cast<double*>(m.hcm); T.Hs = T.Hy + S.nvx;
+    for (int i = tid; i < kNXi2; i += blockDim.x) T.Wb[i] = 0.0;
+    for (int i = tid; i < 2 * S.nvx; i += blockDim.x) T.Hy[i] = 0.0;
+    __syncthreads();
+  }
   for (int g = 0; g < G; ++g) {
     LineS<NI> L, LB;
     {
@@ -810,9 +996,9 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
           base_eval<NI>(wsn, use_ks ? ksc[min(j + 1, npts - 1)] : ks_eval(wsn, L.wpe2), ct, L, T, b1);
           BaseAdj ba;
           double xen, Fn;
-          point_reverse<NI, WM>(ws, b0, b1, has_next, L, T, xs[j] * wa, ba, xen, Fn, LB);
+          point_reverse<NI, GM>(ws, b0, b1, has_next, L, T, xs[j] * wa, ba, xen, Fn, LB, fa);
           ba.xe += cxe; ba.F += cF;
-          base_reverse<NI, WM>(ct, b0, L, T, ba, LB);
+          base_reverse<NI, GM>(ct, b0, L, T, ba, LB, fa);
           cxe = xen; cF = Fn;
           b0 = b1;
           ws = wsn;
@@ -820,7 +1006,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
         if (j0 + kStrip < npts) {  // the strip's right neighbour receives the D-coupling of the last point
           BaseAdj ba;
           ba.k2 = ba.ik = ba.wd = 0.0; ba.xe = cxe; ba.F = cF;
-          base_reverse<NI, WM>(ct, b0, L, T, ba, LB);
+          base_reverse<NI, GM>(ct, b0, L, T, ba, LB, fa);
         }
       }
     }
@@ -862,6 +1048,21 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       }
     }
   }
+  if (GM == 2) {  // table adjoints of this lineout -> global (k_fe_adjoint chains them to f_e)
+    fe_flush_w(fa, T.Wb);
+    fe_flush_h(fa, T.Hy, T.Hs);
+    __syncthreads();
+    for (int i = tid; i < kNXi2; i += blockDim.x) {
+      double* o = K.Wb_out + (size_t)b * kNXi2 + i;
+      *o = accumulate ? *o + T.Wb[i] : T.Wb[i];
+    }
+    for (int i = tid; i < S.nvx; i += blockDim.x) {
+      double* oy = K.Hy_out + (size_t)b * S.nvx + i;
+      double* os = K.Hs_out + (size_t)b * S.nvx + i;
+      *oy = accumulate ? *oy + T.Hy[i] : T.Hy[i];
+      *os = accumulate ? *os + T.Hs[i] : T.Hs[i];
+    }
+  }
   // amplitudes (irf.py:76,126-130)
   if (ht == 0) {
     if (f == TSFF_FEATURE_ELE) { gsum[half * NPk + TSFF_P_AMP1] += a1b; gsum[half * NPk + TSFF_P_AMP2] += a2b; }
@@ -890,7 +1091,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       gsum[o] = (gsum[o] - dot) / p.fsum;
       gsum[TSFF_P_ION0 + 4 * s + TSFF_ION_A] = 0.0;
     }
-    if (!WM) gsum[TSFF_P_M] = 0.0;
+    if (GM != 1) gsum[TSFF_P_M] = 0.0;
   }
   __syncthreads();
   if (tid < NPk) {

@@ -183,3 +183,74 @@ class SphericalHarmonics:
             f = f + flm * real_sph_harm(l, m, self.phi, self.th)
         f = np.maximum(f, 1e-32)
         return f / (np.sum(f) * (self.vx[1] - self.vx[0]) ** 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# Arbitrary1V (base.py:157-204): free-form 1-D distribution function.  Stored leaf: fval [nvx];
+# f_e = normalise(10 ** -((7 smooth(fval)) ** 2)), smooth = forward-backward second-order Butterworth filter
+# (base.py:41-97; f_sampling = 100, f_cutoff = 6).  The filter is linear and homogeneous in its input (the scan is
+# seeded with the first two samples), so it is applied as a constant [nvx, nvx] matrix and its adjoint is the transpose.
+# ---------------------------------------------------------------------------------------------
+def _butterworth_pass(signal: np.ndarray, f_sampling: float, f_cutoff: float) -> np.ndarray:
+    ff = f_cutoff / f_sampling
+    ita = 1.0 / np.tan(np.pi * ff)
+    q = np.sqrt(2.0)
+    b0 = 1.0 / (1.0 + q * ita + ita**2)
+    b1, b2 = 2 * b0, b0
+    a1 = 2.0 * (ita**2 - 1.0) * b0
+    a2 = -(1.0 - q * ita + ita**2) * b0
+    x1, x2, y1, y2 = signal[1], signal[0], signal[1], signal[0]
+    out = []
+    for x in signal[2:]:
+        y = b0 * x + b1 * x1 + b2 * x2 + a1 * y1 + a2 * y2
+        x1, x2, y1, y2 = x, x1, y, y1
+        out.append(y)
+    out = np.array(out)
+    return np.concatenate((out[0:1], out[0:1], out))
+
+
+@lru_cache(maxsize=8)
+def butterworth_matrix(n: int, f_sampling: float = 100.0, f_cutoff: float = 6.0) -> np.ndarray:
+    """S with smooth(x) = S @ x for method "forward_backward" (forward pass, then the same pass on the flipped
+    signal, flipped back)."""
+    S = np.zeros((n, n))
+    eye = np.eye(n)
+    for j in range(n):
+        fwd = _butterworth_pass(eye[:, j], f_sampling, f_cutoff)
+        S[:, j] = _butterworth_pass(fwd[::-1], f_sampling, f_cutoff)[::-1]
+    return S
+
+
+def arbitrary_1v_init(m: float, nvx: int) -> np.ndarray:
+    """Arbitrary1V.init_dlm (base.py:188-196): fval of a super-Gaussian of order m (v_th = 1 here)."""
+    vx = velocity_grid(nvx)
+    alpha = np.sqrt(3.0 * gamma(3.0 / m) / 2.0 / gamma(5.0 / m))
+    cst = m / (4.0 * np.pi * alpha**3.0 * gamma(3.0 / m))
+    f = cst * np.exp(-(np.abs(vx / alpha) ** m))
+    f = f / np.sum(f) / (vx[1] - vx[0])
+    return np.sqrt(-np.log10(f)) / 7.0
+
+
+def arbitrary_1v(fval: np.ndarray) -> np.ndarray:
+    """Arbitrary1V.__call__ (base.py:201-204) for fval [..., nvx] -> f_e [..., nvx]."""
+    fval = np.asarray(fval, dtype=np.float64)
+    nvx = fval.shape[-1]
+    dv = 12.0 / nvx
+    u = fval @ butterworth_matrix(nvx).T
+    f = np.power(10.0, -((7.0 * u) ** 2.0))
+    return f / np.sum(f, axis=-1, keepdims=True) / dv
+
+
+def arbitrary_1v_vjp(fval: np.ndarray, g_fe: np.ndarray) -> np.ndarray:
+    """d loss / d fval given g_fe = d loss / d f_e (chain rule of arbitrary_1v)."""
+    fval = np.asarray(fval, dtype=np.float64)
+    nvx = fval.shape[-1]
+    dv = 12.0 / nvx
+    S = butterworth_matrix(nvx)
+    u = fval @ S.T
+    f = np.power(10.0, -((7.0 * u) ** 2.0))
+    Z = np.sum(f, axis=-1, keepdims=True)
+    fe = f / Z / dv
+    g_f = (g_fe / dv - np.sum(g_fe * fe, axis=-1, keepdims=True)) / Z
+    g_u = g_f * (-np.log(10.0) * f) * (98.0 * u)
+    return g_u @ S

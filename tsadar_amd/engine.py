@@ -398,8 +398,9 @@ class Engine:
             w[2] *= e_norm**2
         return w
 
-    def loss_grad(self, params, batch, weights, grad_mask, fe=None, want_spectra=False, out=None):
-        """-> (loss_terms[3], grad[B, NP], ThryE, ThryI) as CUDA tensors; nothing is synchronised."""
+    def loss_grad(self, params, batch, weights, grad_mask, fe=None, want_spectra=False, out=None, want_fe_grad=False):
+        """-> (loss_terms[3], grad[B, NP], ThryE, ThryI) as CUDA tensors; nothing is synchronised.
+        ``want_fe_grad`` (fe_mode PER_LINEOUT): a fifth result, d loss / d fe [B, nvx]."""
         torch = self.torch
         X = self.dev(params).reshape(-1, self.NP)
         B = X.shape[0]
@@ -419,6 +420,14 @@ class Engine:
         w = np.ascontiguousarray(weights, dtype=np.float64)
         gm = np.ascontiguousarray(grad_mask, dtype=np.uint8)
         self._sync_stream()
+        if want_fe_grad:
+            gfe = torch.empty((B, self.nvx), dtype=torch.float64, device=self.device)
+            rc = self.lib.tsff_loss_grad_fe(self.h, self._ptr(X), self._ptr(fe_d), self._ptr(ed), self._ptr(idt), self._ptr(ea),
+                                            self._ptr(ia), self._ptr(ne_), self._ptr(ni_), B, w.ctypes.data_as(L.c_double_p),
+                                            gm.ctypes.data_as(L.c_uint8_p), self._ptr(terms), self._ptr(grad), self._ptr(gfe),
+                                            self._ptr(E), self._ptr(I))
+            L.check(self.lib, self.h, rc)
+            return terms, grad, E, I, gfe
         rc = self.lib.tsff_loss_grad(self.h, self._ptr(X), self._ptr(fe_d), self._ptr(ed), self._ptr(idt), self._ptr(ea),
                                      self._ptr(ia), self._ptr(ne_), self._ptr(ni_), B, w.ctypes.data_as(L.c_double_p),
                                      gm.ctypes.data_as(L.c_uint8_p), self._ptr(terms), self._ptr(grad), self._ptr(E), self._ptr(I))

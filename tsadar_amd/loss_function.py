@@ -39,6 +39,7 @@ class LossFunction:
         self.distributed = distributed
         self.pg = process_group
         self.unravel_weights = None  # set by the caller exactly as in loops.py:41
+        self._gfe = None
         self._dev_batch_key = None
         self._dev_batch = None
 
@@ -73,6 +74,15 @@ class LossFunction:
         world, rank = self._world()
         w = eng.loss_weights(B * world, self.i_norm, self.e_norm, self.cfg["data"]["ion_loss_scale"])
         db = self._device_batch(eng, batch, B)
+        if ts_params.fval is not None:  # free-form f_e: explicit tables in, d loss / d fe out
+            from . import distribution as Dist
+
+            fe = Dist.arbitrary_1v(ts_params.fval)
+            terms, grad, E, I, gfe = eng.loss_grad(X, db, w, ts_params.grad_mask(), fe=fe, want_spectra=want_spectra,
+                                                   want_fe_grad=True)
+            self._gfe = gfe
+            return eng, w, terms, grad, E, I
+        self._gfe = None
         terms, grad, E, I = eng.loss_grad(X, db, w, ts_params.grad_mask(), want_spectra=want_spectra)
         return eng, w, terms, grad, E, I
 
@@ -95,14 +105,36 @@ class LossFunction:
         eng, w, terms, grad, E, I = self._evaluate(ts_params, batch, want_spectra=not lbfgs)
         act = [s for _, s in ts_params.slots.active_leaves]
         gact = grad[:, act].t().contiguous()  # [P, B_local], ravel order
+        if getattr(self, "_gfe", None) is not None and ts_params.slots.fval_active:
+            gact = torch.cat([gact, self._gfe.t().contiguous()])  # nvx more rows: d loss / d fe, chained on the host
         terms, gflat = D.allreduce_loss_grad(terms, gact, world, rank, self.pg)  # the one collective per step
         host = torch.cat([terms, gflat]).cpu().numpy()  # single D2H copy: 3 + P*B doubles
         value = float(np.dot(host[:3], w))
         flat = host[3:]
+        if getattr(self, "_gfe", None) is not None and ts_params.slots.fval_active:
+            flat = self._chain_fval(flat, len(act), diff_global)
         if lbfgs:
             return value, flat
         aux = [E.cpu().numpy() if E is not None else None, ts_params()]
         return (value, aux), diff_global.like(flat)
+
+    def _chain_fval(self, flat, P, diff_global):
+        """[P + nvx, B] rows (scalar leaves, then d loss / d fe) -> the reference's ravel order with the
+        Arbitrary1V chain rule applied (d loss / d fval = J^T d loss / d fe, base.py:201-204)."""
+        from . import distribution as Dist
+
+        fv = next(v for (_, s), v in zip(diff_global.slots, diff_global.values) if s == tree.FVAL_SLOT)
+        Bg, nvx = fv.shape
+        rows = flat.reshape(P + nvx, Bg)
+        gfval = Dist.arbitrary_1v_vjp(fv, rows[P:].T)
+        out, k = [], 0
+        for _, s in diff_global.slots:
+            if s == tree.FVAL_SLOT:
+                out.append(gfval.ravel())
+            else:
+                out.append(rows[k])
+                k += 1
+        return np.concatenate(out)
 
     def loss(self, weights, batch: Dict):
         """loss_function.py:344-362."""

@@ -69,6 +69,10 @@ class SlotMap:
         if self.has_m:
             self._affine(L.P_M, {"active": bool(fe.get("active", False))}, 3.0, 2.0)  # base.py:252-253
             self.leaves.append((("electron", "m"), L.P_M))
+        # free-form 1-D distribution (Arbitrary1V): nvx trainable values per lineout, raveled right after (Te, ne)
+        self.has_fval = self.fe_type == "arbitrary" and int(fe.get("dim", 1)) == 1
+        self.fval_active = self.has_fval and bool(fe.get("active", False))
+        self.n_electron_leaves = len(self.leaves)
         for i, sp in enumerate(self.species):
             ic = param_cfg[sp]
             o = L.P_ION0 + 4 * i
@@ -133,6 +137,12 @@ class ThomsonParams:
         g = param_cfg["general"]
         for k in GENERAL_KEYS:
             X[:, _GENERAL_SLOT[k]] = self._init(g[k]["val"], _GENERAL_SLOT[k])
+        self.fval = None
+        if sm.has_fval:  # ts_params.py:143-147: one Arbitrary1V per lineout
+            from . import distribution as D
+
+            fv = D.arbitrary_1v_init(float(el["fe"]["params"]["init_m"]), int(el["fe"]["nvx"]))
+            self.fval = np.tile(fv[None, :], (B, 1))
         # 2-D distribution function (ts_params.py:152-163): one shared table, never batched
         self.fe_dim = int(el.get("fe", {}).get("dim", 1))
         self.fval2d = None
@@ -165,6 +175,8 @@ class ThomsonParams:
     def copy(self) -> "ThomsonParams":
         other = copy.copy(self)
         other.X = self.X.copy()
+        if self.fval is not None:
+            other.fval = self.fval.copy()
         return other
 
     # ---- scipy-facing: the reference's ravel_pytree(diff_params) ordering -----------------------
@@ -204,6 +216,10 @@ class ThomsonParams:
         out = {"electron": {"Te": sq(P[:, L.P_TE]), "ne": sq(P[:, L.P_NE])}, "general": {}}
         if sm.has_m:
             out["electron"]["m"] = sq(P[:, L.P_M])
+        if self.fval is not None:  # Arbitrary1V.get_unnormed_params: {"f": self()}
+            from . import distribution as D
+
+            out["electron"]["f"] = sq(D.arbitrary_1v(self.fval))
         for k in GENERAL_KEYS:
             out["general"][k] = sq(P[:, _GENERAL_SLOT[k]])
         for i, sp in enumerate(sm.species):
@@ -228,6 +244,11 @@ class ThomsonParams:
             vx = np.tile(D.velocity_grid(nvx)[None, :], (len(m), 1))
             out["electron"]["fe"] = fe if self.batch else fe[0]
             out["electron"]["v"] = vx if self.batch else vx[0]
+        if self.fval is not None:
+            fe = D.arbitrary_1v(self.fval)
+            out["electron"].pop("f", None)
+            out["electron"]["fe"] = fe if self.batch else fe[0]
+            out["electron"]["v"] = np.tile(D.velocity_grid(nvx)[None, :], (fe.shape[0], 1)) if self.batch else D.velocity_grid(nvx)
         if self.fe_dim == 2:
             out["electron"]["fe"] = self.sph() if self.sph is not None else D.arbitrary_2v(self.fval2d, self.learn_log)
             out["electron"]["v"] = D.velocity_grid(nvx)
@@ -240,7 +261,7 @@ class ThomsonParams:
         for k in pd:
             fitted[k] = {}
             for k2 in pd[k]:
-                if k2 == "m":
+                if k2 in ("m", "f"):
                     if param_cfg[k]["fe"]["active"]:
                         fitted[k][k2] = pd[k][k2]
                         n += 1

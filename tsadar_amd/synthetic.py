@@ -98,7 +98,7 @@ def draw_params(cfg: dict, B: int, rng: np.random.Generator, activate: bool = Tr
     return tp
 
 
-def make_batch(engine, truth: ThomsonParams, rng: np.random.Generator, noise_level: float = 0.01) -> dict:
+def make_batch(engine, truth: ThomsonParams, rng: np.random.Generator, noise_level: float = 0.01, fe=None) -> dict:
     """Synthetic 'measured' spectra resident on the GPU: the engine's own forward model at the truth
     parameters with unit amplitudes, times (1 + 1 % Gaussian noise); amplitudes = row maximum inside
     the fit ranges (the reference's lineouts.py:127-150).  noise_e / noise_i are None (= 0)."""
@@ -106,7 +106,7 @@ def make_batch(engine, truth: ThomsonParams, rng: np.random.Generator, noise_lev
 
     B = truth.X.shape[0]
     ones = np.ones(B)
-    E, I = engine.forward(truth.to_matrix(), ones, ones)
+    E, I = engine.forward(truth.to_matrix(), ones, ones, fe=fe)
     gen = torch.Generator(device=E.device)
     gen.manual_seed(int(rng.integers(1 << 31)))
     E = E * (1 + noise_level * torch.randn(E.shape, dtype=E.dtype, device=E.device, generator=gen))

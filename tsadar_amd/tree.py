@@ -13,19 +13,27 @@ import numpy as np
 from .params import ThomsonParams
 
 
+FVAL_SLOT = -1  # pseudo-slot of the free-form distribution-function leaf (Arbitrary1V.fval, [B, nvx])
+
+
 class DiffParams:
-    """The trainable leaves of a ThomsonParams: {slot: array[B]} in ravel order."""
+    """The trainable leaves of a ThomsonParams in ravel order: arrays [B] per scalar leaf; the free-form
+    distribution function is one entry of shape [B, nvx] (B leaves of nvx values each, lineout-major, exactly the
+    order ravel_pytree gives the list of Arbitrary1V modules)."""
 
     def __init__(self, slots, values):
         self.slots = slots  # list of (name, slot)
-        self.values = values  # list of arrays [B]
+        self.values = values  # list of arrays [B] (or [B, nvx])
 
     def ravel(self) -> np.ndarray:
-        return np.concatenate(self.values) if self.values else np.zeros(0)
+        return np.concatenate([np.ravel(v) for v in self.values]) if self.values else np.zeros(0)
 
     def like(self, flat: np.ndarray) -> "DiffParams":
-        B = self.values[0].shape[0] if self.values else 0
-        return DiffParams(self.slots, [np.asarray(flat[i * B : (i + 1) * B], dtype=np.float64) for i in range(len(self.slots))])
+        out, o = [], 0
+        for v in self.values:
+            out.append(np.asarray(flat[o : o + v.size], dtype=np.float64).reshape(v.shape))
+            o += v.size
+        return DiffParams(self.slots, out)
 
     def as_dict(self):
         return {name: v for (name, _), v in zip(self.slots, self.values)}
@@ -39,20 +47,32 @@ class StaticParams:
 
 
 def get_filter_spec(cfg_params, ts_params: ThomsonParams):
-    """Which leaves are trainable: [(name, slot)] in ravel order."""
-    return list(ts_params.slots.active_leaves)
+    """Which leaves are trainable: [(name, slot)] in ravel order (electron leaves, then the free-form distribution
+    function, then ions and general: the field order of ElectronParams, ts_params.py:46-56)."""
+    sm = ts_params.slots
+    spec = []
+    for k, (name, s) in enumerate(sm.leaves):
+        if k == sm.n_electron_leaves and sm.fval_active:
+            spec.append((("electron", "fval"), FVAL_SLOT))
+        if sm.active[s]:
+            spec.append((name, s))
+    return spec
 
 
 def partition(ts_params: ThomsonParams, filter_spec=None) -> Tuple[DiffParams, StaticParams]:
     spec = filter_spec if filter_spec is not None else get_filter_spec(None, ts_params)
-    return DiffParams(list(spec), [ts_params.X[:, s].copy() for _, s in spec]), StaticParams(ts_params)
+    vals = [ts_params.fval.copy() if s == FVAL_SLOT else ts_params.X[:, s].copy() for _, s in spec]
+    return DiffParams(list(spec), vals), StaticParams(ts_params)
 
 
 def combine(a, b) -> ThomsonParams:
     diff, static = (a, b) if isinstance(a, DiffParams) else (b, a)
     out = static.ts_params.copy()
     for (_, s), v in zip(diff.slots, diff.values):
-        out.X[:, s] = v
+        if s == FVAL_SLOT:
+            out.fval = np.array(v, dtype=np.float64)
+        else:
+            out.X[:, s] = v
     return out
 
 
