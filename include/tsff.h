@@ -172,6 +172,12 @@ int tsff_form_factor(tsff_handle *h, int32_t feature, const double *phys, const 
  * its golden vectors are not part of the reference source tree. */
 int tsff_form_factor_2d(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
                         int32_t shared_fe, double ud_angle_deg, double va_angle_deg, int32_t B, double *P);
+/* The same for the points [point_begin, point_end) of the flat (lineout, gradient point, wavelength, angle) list only;
+ * the rest of P is left untouched (point_end < 0: to the end).  This is the unit of work the reference shards across
+ * devices (parallel_calc_all_chi_vals, form_factor.py:431-447): each rank evaluates its range, the ranges are gathered. */
+int tsff_form_factor_2d_range(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
+                              int32_t shared_fe, double ud_angle_deg, double va_angle_deg, int32_t B,
+                              int64_t point_begin, int64_t point_end, double *P);
 
 /* Angular (ARTS) instrument chain for one image P[G][npts][n_angles] (device; from tsff_form_factor_2d or, for a 1-D
  * distribution function, tsff_form_factor): FitModel.electron_spectrum "angular_full" branch

@@ -10,6 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsff.so")
+LIB_PATH = os.environ.get("TSFF_LIBRARY", LIB_PATH)  # A/B experiments: another in-tree build of the same ABI
 
 ABI_VERSION = 4
 MAX_ION = 4
@@ -107,6 +108,8 @@ _SIGNATURES = {
     "tsff_chi_table": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
     "tsff_form_factor": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp]),
     "tsff_form_factor_2d": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, _vp]),
+    "tsff_form_factor_2d_range": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32,
+                                            C.c_int64, C.c_int64, _vp]),
     "tsff_ats_setup": (C.c_int, [_vp, C.POINTER(TsffAtsConfig)]),
     "tsff_ats_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "tsff_forward": (C.c_int, [_vp] + [_vp] * 6 + [C.c_int32, _vp, _vp]),

@@ -9,6 +9,10 @@
 
 #include "../../include/tsff.h"
 
+#ifndef TSFF_BRANCHFREE
+#define TSFF_BRANCHFREE 1  // table lookups without divergent branches (one scheduling region per point)
+#endif
+
 namespace tsff {
 
 constexpr int kThreads = 256;    // 4 wavefronts of 64
@@ -178,11 +182,19 @@ __device__ __forceinline__ void w_lookup(const double* W, double xe, double& w, 
   double u = (xe - kXi2_0) * kXi2_ih;
   int i = (int)u;
   i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
-  const double t = (xe - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
+  double t = (xe - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
   const double a = W[i], b = W[i + 1];
+#if TSFF_BRANCHFREE
+  // straight-line form: one scheduling region per point, so the LDS reads can be hoisted over the arithmetic
+  t = fmin(fmax(t, 0.0), 1.0);  // outside the table the clamped interval reproduces the end value
+  const double d = b - a;
+  w = __builtin_fma(t, d, a);
+  dw = (xe < kXi2_0 || xe > xlast) ? 0.0 : d * kXi2_ih;
+#else
   if (xe < kXi2_0) { w = W[0]; dw = 0.0; }
   else if (xe > xlast) { w = W[kNXi2 - 1]; dw = 0.0; }
   else { w = a + t * (b - a); dw = (b - a) * kXi2_ih; }
+#endif
 }
 
 // cubic coefficients of interval i of the Hermite interpolant in t = (x - vx_i)/dv:
@@ -200,11 +212,19 @@ __device__ __forceinline__ void hermite_lookup_c(const Tables& T, double x, doub
   i = i < 0 ? 0 : (i > T.nvx - 2 ? T.nvx - 2 : i);
   const double t = (x - (T.vx0 + i * T.dv)) * T.idv;
   const double2 c01 = T.hc[2 * i], c23 = T.hc[2 * i + 1];
+#if TSFF_BRANCHFREE
+  const bool out = x < T.vx0 || x > T.vxlast;
+  const double Hi = c01.x + t * (c01.y + t * (c23.x + t * c23.y));
+  const double dHi = (c01.y + t * (2.0 * c23.x + 3.0 * t * c23.y)) * T.idv;
+  H = out ? -50.0 : Hi;
+  dH = out ? 0.0 : dHi;
+#else
   if (x < T.vx0 || x > T.vxlast) { H = -50.0; dH = 0.0; }
   else {
     H = c01.x + t * (c01.y + t * (c23.x + t * c23.y));
     dH = (c01.y + t * (2.0 * c23.x + 3.0 * t * c23.y)) * T.idv;
   }
+#endif
 }
 
 // interpax.interp1d(x, vx, ln fe, method="cubic", extrap=[-50,-50])  (form_factor.py:256,263)
@@ -438,6 +458,13 @@ __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& 
   const double dr = b.x - a.x, di = b.y - a.y;
   zr = a.x + t * dr; zi = a.y + t * di; dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
   const bool out = xi < kXi2_0 || xi > xlast;
+#if TSFF_BRANCHFREE
+  {
+    const double i2 = frcp(xi * xi);
+    const double di2 = -2.0 * i2 * i2 * xi;
+    zr = out ? i2 : zr; zi = out ? 0.0 : zi; dzr = out ? di2 : dzr; dzi = out ? 0.0 : dzi;
+  }
+#else
 #if TSFF_FASTPATH
   if (__any(out))
 #endif
@@ -445,6 +472,7 @@ __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& 
     const double i2 = frcp(xi * xi);
     if (out) { zr = i2; zi = 0.0; dzr = -2.0 * i2 * i2 * xi; dzi = 0.0; }
   }
+#endif
 }
 
 // P(lambda_j, theta_a) of one gradient point (form_factor.py:247-296)

@@ -1187,141 +1187,205 @@ __device__ __forceinline__ void hermite_weights(int c, int n, double t, double w
   else { w[1] -= 0.5 * h11; w[3] += 0.5 * h11; }
 }
 
-// LDS: true -> the nv x nv table is staged once per (persistent) workgroup in LDS (nv <= 128: 128 KB), the
-// workgroup then loops over points; false -> the table is read through L1/L2 (any nv).
-template <int NI, bool LDS>
-__global__ __launch_bounds__(kThreads) void k_form_factor_2d(KStatic S, const double* __restrict__ phys,
-                                                             const double* __restrict__ fe2d, int nv, int shared_fe,
-                                                             double ud_ang, double va_ang, int f, long npoint,
-                                                             double* __restrict__ P) {
+// one bicubic sample of the table at (xq, yq).  When every lane of the wavefront is in an interior cell (the vast
+// majority of samples) the Catmull-Rom weights and 4 x 4 consecutive loads need no index clamps; otherwise the whole
+// wavefront takes the general path (edge cells, extrapolated samples) through hermite_weights.
+__device__ __forceinline__ double bicubic_sample(const double* __restrict__ F, int nv, int pitch, double v0, double dv,
+                                                 double idv, double xq, double yq) {
+  const double ux = (xq - v0) * idv, uy = (yq - v0) * idv;
+  const double fx = floor(ux), fy = floor(uy);
+  int cx = (int)fx, cy = (int)fy;
+  if (__all(cx >= 1 && cx <= nv - 3 && cy >= 1 && cy <= nv - 3)) {  // wavefront-uniform: no divergence
+    const double tx = (xq - (v0 + cx * dv)) * idv, ty = (yq - (v0 + cy * dv)) * idv;
+    double wx[4], wy[4];
+    {
+      const double t2 = tx * tx, t3 = t2 * tx;
+      const double h10 = t3 - 2.0 * t2 + tx, h11 = t3 - t2;
+      wx[0] = -0.5 * h10;
+      wx[1] = (2.0 * t3 - 3.0 * t2 + 1.0) - 0.5 * h11;
+      wx[2] = (-2.0 * t3 + 3.0 * t2) + 0.5 * h10;
+      wx[3] = 0.5 * h11;
+    }
+    {
+      const double t2 = ty * ty, t3 = t2 * ty;
+      const double h10 = t3 - 2.0 * t2 + ty, h11 = t3 - t2;
+      wy[0] = -0.5 * h10;
+      wy[1] = (2.0 * t3 - 3.0 * t2 + 1.0) - 0.5 * h11;
+      wy[2] = (-2.0 * t3 + 3.0 * t2) + 0.5 * h10;
+      wy[3] = 0.5 * h11;
+    }
+    const double* __restrict__ r0 = F + (size_t)(cx - 1) * pitch + (cy - 1);
+    double v = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double* __restrict__ row = r0 + (size_t)m * pitch;
+      double r = wy[0] * row[0];
+      r += wy[1] * row[1];
+      r += wy[2] * row[2];
+      r += wy[3] * row[3];
+      v += wx[m] * r;
+    }
+    return v;
+  }
+  cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
+  cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
+  double wx[4], wy[4];
+  hermite_weights(cx, nv, (xq - (v0 + cx * dv)) * idv, wx);
+  hermite_weights(cy, nv, (yq - (v0 + cy * dv)) * idv, wy);
+  double v = 0.0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int rx = min(max(cx - 1 + m, 0), nv - 1);   // (clamped rows carry zero weight)
+    const double* __restrict__ row = F + (size_t)rx * pitch;
+    double r = 0.0;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) r += wy[n] * row[min(max(cy - 1 + n, 0), nv - 1)];
+    v += wx[m] * r;
+  }
+  return v;
+}
+
+// LDS: true -> the nv x nv table is staged once per (persistent) workgroup in LDS (nv <= 128: 128 KB); false -> the
+// table is read through L1/L2 (any nv).  A workgroup is kG2 = 4 groups of 256 threads that work on four different
+// points at once and share the table: 4 wavefronts per SIMD hide the latency of the 16 table reads per sample (one
+// 256-thread workgroup per CU, all the 128 KB table allows, leaves one wavefront per SIMD waiting on LDS).  The
+// per-point scalars are computed by one thread per group and passed through LDS so that the sampling loop stays
+// within the 128 registers of a 1024-thread workgroup.  One table per launch (the host loops over lineouts when every
+// lineout has its own).
+#ifndef TSFF_2D_GROUPS_LDS
+#define TSFF_2D_GROUPS_LDS 4
+#endif
+#ifndef TSFF_2D_GROUPS_L2
+#define TSFF_2D_GROUPS_L2 1
+#endif
+constexpr int kSc2 = 40;  // doubles of per-group scalar scratch
+// LDS rows are padded by one double: with a power-of-two pitch every row starts in the same bank and the lanes of a
+// wavefront (neighbouring points of a rotated line) collide whenever the line runs along the first table axis
+__host__ __device__ inline int pitch2d(int nv, bool lds) { return lds ? nv + 1 : nv; }
+__host__ __device__ inline size_t smem2d_doubles(int nv, bool lds, int ng) {
+  return (size_t)ng * (6 * (size_t)nv + 8 + kSc2) + (lds ? (size_t)nv * pitch2d(nv, true) : 0);
+}
+template <int NI, bool LDS, int kG2>
+__global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d(KStatic S, const double* __restrict__ phys,
+                                                                   const double* __restrict__ Fg, int nv,
+                                                                   double ud_ang, double va_ang, int f, long pbegin,
+                                                                   long pend, double* __restrict__ P) {
   extern __shared__ __align__(16) unsigned char smem[];
-  double* f1 = reinterpret_cast<double*>(smem);   // [nv] projected distribution
-  double* d1 = f1 + nv;                           // [nv] its gradient
-  double* part = d1 + nv;                         // [4][nv] partial column sums
-  double* red = part + 4 * nv;                    // [8]
-  double* Fl = red + 8;                           // [nv][nv] (LDS variant)
-  const int tid = threadIdx.x;
+  const int grp = threadIdx.x >> 8, gt = threadIdx.x & (kThreads - 1);
+  double* gbase = reinterpret_cast<double*>(smem) + (size_t)grp * (6 * (size_t)nv + 8 + kSc2);
+  double* f1 = gbase;              // [nv] projected distribution
+  double* d1 = f1 + nv;            // [nv] its gradient
+  double* part = d1 + nv;          // [4][nv] partial column sums
+  double* red = part + 4 * nv;     // [8]
+  double* sc = red + 8;            // [kSc2] point scalars
+  double* Fl = reinterpret_cast<double*>(smem) + (size_t)kG2 * (6 * (size_t)nv + 8 + kSc2);  // [nv][nv] (LDS variant)
   const int NA = S.n_angles, G = S.G, npts = S.npts;
   // thread -> (column iy, part of the ix range): nparts = 256 / nvp with nvp = nv rounded up to 64, 128 or 256
   const int nvp = nv <= 64 ? 64 : (nv <= 128 ? 128 : 256);
   const int nparts = nv <= 256 ? kThreads / nvp : 1;
   const double dv = 12.0 / nv, v0 = -6.0 + 0.5 * dv, idv = 1.0 / dv;  // base.py:333-335
-  int b_loaded = -1;
-  for (long pid = blockIdx.x; pid < npoint; pid += gridDim.x) {
-    const int a = (int)(pid % NA), j = (int)((pid / NA) % npts), g = (int)((pid / ((long)NA * npts)) % G);
-    const int b = (int)(pid / ((long)NA * npts * G));
-    const double* __restrict__ Fg = fe2d + (shared_fe ? 0 : (size_t)b * nv * nv);
-    if (LDS && (b_loaded < 0 || (!shared_fe && b != b_loaded))) {
-      __syncthreads();
-      for (int i = tid; i < nv * nv; i += kThreads) Fl[i] = Fg[i];
-      b_loaded = b;
-    }
-    const double* __restrict__ F = LDS ? Fl : Fg;
-    Phys<NI> p;
-    load_phys<NI>(phys + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, false, p);
-    LineS<NI> L;
-    make_lines<NI>(p, S.lam_shift[f], g, G, L);
-    // ---- point scalars ----
-    const double ws = S.omgs[f][j], th = S.sa_rad[a];
-    const double ks = ks_eval(ws, L.wpe2);
-    const double kx = cos(th) * ks - L.kL, ky = sin(th) * ks;
-    const double k2 = kx * kx + ky * ky, k = sqrt(k2);
-    const double Vx = L.Vd * cos(va_ang), Vy = L.Vd * sin(va_ang);
-    const double Ux = L.Ud * cos(ud_ang), Uy = L.Ud * sin(ud_ang);
-    const double wd = (ws - L.wL) - (kx * Vx + ky * Vy);
-    const double aa = wd / k2;
-    const double xex = (aa * kx - Ux) * L.ivTe, xey = (aa * ky - Uy) * L.ivTe;
-    const double xmag = sqrt(xex * xex + xey * xey);
-    const double beta = atan(xey / xex) + (xex >= 0.0 ? 0.0 : kPi);   // heaviside(x, 1) = 1 at x == 0
-    const double cb = cos(beta), sb = sin(beta);
+  const int pitch = pitch2d(nv, LDS);
+  if (LDS) {
+    for (int i = threadIdx.x; i < nv * nv; i += kG2 * kThreads) Fl[(i / nv) * pitch + (i % nv)] = Fg[i];
+  }
+  const double* __restrict__ F = LDS ? Fl : Fg;
+  const long stride = (long)gridDim.x * kG2;
+  for (long base = pbegin + (long)blockIdx.x * kG2; base < pend; base += stride) {
+    const long pid = base + grp;
+    const bool active = pid < pend;  // every group runs the same barrier sequence; idle groups skip the work
     __syncthreads();
-    // ---- rotate + project ----
-    if (nv <= 256) {
-      const int iy = tid % nvp, pt = tid / nvp;
-      if (iy < nv) {
-        const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
-        const double y = v0 + iy * dv;
-        double acc = 0.0;
-        for (int ix = ix0; ix < ix1; ++ix) {
-          const double x = v0 + ix * dv;
-          const double xq = x * cb - y * sb, yq = x * sb + y * cb;
-          int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
-          cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
-          cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
-          double wx[4], wy[4];
-          hermite_weights(cx, nv, (xq - (v0 + cx * dv)) * idv, wx);
-          hermite_weights(cy, nv, (yq - (v0 + cy * dv)) * idv, wy);
-          double v = 0.0;
+    if (active && gt == 0) {
+      const int a = (int)(pid % NA), j = (int)((pid / NA) % npts), g = (int)((pid / ((long)NA * npts)) % G);
+      const int b = (int)(pid / ((long)NA * npts * G));
+      Phys<NI> p;
+      load_phys<NI>(phys + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, false, p);
+      LineS<NI> L;
+      make_lines<NI>(p, S.lam_shift[f], g, G, L);
+      // ---- point scalars (form_factor.py:515-558) ----
+      const double ws = S.omgs[f][j], th = S.sa_rad[a];
+      const double ks = ks_eval(ws, L.wpe2);
+      const double kx = cos(th) * ks - L.kL, ky = sin(th) * ks;
+      const double k2 = kx * kx + ky * ky, k = sqrt(k2);
+      const double Vx = L.Vd * cos(va_ang), Vy = L.Vd * sin(va_ang);
+      const double Ux = L.Ud * cos(ud_ang), Uy = L.Ud * sin(ud_ang);
+      const double wd = (ws - L.wL) - (kx * Vx + ky * Vy);
+      const double aa = wd / k2;
+      const double xex = (aa * kx - Ux) * L.ivTe, xey = (aa * ky - Uy) * L.ivTe;
+      const double beta = atan(xey / xex) + (xex >= 0.0 ? 0.0 : kPi);   // heaviside(x, 1) = 1 at x == 0
+      sc[0] = cos(beta); sc[1] = sin(beta); sc[2] = sqrt(xex * xex + xey * xey);
+      sc[3] = k2; sc[4] = k; sc[5] = wd; sc[6] = ws; sc[7] = L.a_e; sc[8] = L.ivTe; sc[9] = L.wL; sc[10] = L.pref;
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const int rx = min(max(cx - 1 + m, 0), nv - 1);   // (clamped rows carry zero weight)
-            const double* __restrict__ row = F + (size_t)rx * nv;
-            double r = 0.0;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) r += wy[n] * row[min(max(cy - 1 + n, 0), nv - 1)];
-            v += wx[m] * r;
+      for (int s = 0; s < NI; ++s) { sc[12 + 3 * s] = L.ixi[s]; sc[13 + 3 * s] = L.a_i[s]; sc[14 + 3 * s] = L.cs[s]; }
+    }
+    __syncthreads();
+    const double cb = sc[0], sb = sc[1], xmag = sc[2];
+    // ---- rotate + project (:300-324, 371) ----
+    if (active) {
+      if (nv <= 256) {
+        const int iy = gt % nvp, pt = gt / nvp;
+        if (iy < nv) {
+          const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
+          const double y = v0 + iy * dv;
+          double acc = 0.0;
+          for (int ix = ix0; ix < ix1; ++ix) {
+            const double x = v0 + ix * dv;
+            const double xq = x * cb - y * sb, yq = x * sb + y * cb;
+            acc += bicubic_sample(F, nv, pitch, v0, dv, idv, xq, yq);
           }
-          acc += v;
+          part[pt * nv + iy] = acc;
         }
-        part[pt * nv + iy] = acc;
+      } else {
+        for (int iy = gt; iy < nv; iy += kThreads) {
+          const double y = v0 + iy * dv;
+          double acc = 0.0;
+          for (int ix = 0; ix < nv; ++ix) {
+            const double x = v0 + ix * dv;
+            const double xq = x * cb - y * sb, yq = x * sb + y * cb;
+            acc += bicubic_sample(F, nv, pitch, v0, dv, idv, xq, yq);
+          }
+          part[iy] = acc;
+        }
       }
-      __syncthreads();
-      for (int i = tid; i < nv; i += kThreads) {
+    }
+    __syncthreads();
+    if (active) {
+      for (int i = gt; i < nv; i += kThreads) {
         double sacc = 0.0;
         for (int q = 0; q < nparts; ++q) sacc += part[q * nv + i];
         f1[i] = sacc * dv;
       }
-    } else {
-      for (int iy = tid; iy < nv; iy += kThreads) {
-        const double y = v0 + iy * dv;
-        double acc = 0.0;
-        for (int ix = 0; ix < nv; ++ix) {
-          const double x = v0 + ix * dv;
-          const double xq = x * cb - y * sb, yq = x * sb + y * cb;
-          int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
-          cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
-          cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
-          double wx[4], wy[4];
-          hermite_weights(cx, nv, (xq - (v0 + cx * dv)) * idv, wx);
-          hermite_weights(cy, nv, (yq - (v0 + cy * dv)) * idv, wy);
-          double v = 0.0;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const int rx = min(max(cx - 1 + m, 0), nv - 1);
-            const double* __restrict__ row = F + (size_t)rx * nv;
-            double r = 0.0;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) r += wy[n] * row[min(max(cy - 1 + n, 0), nv - 1)];
-            v += wx[m] * r;
-          }
-          acc += v;
-        }
-        f1[iy] = acc * dv;
+    }
+    __syncthreads();
+    if (active) {
+      for (int i = gt; i < nv; i += kThreads) {
+        double gd;
+        if (i == 0) gd = (f1[1] - f1[0]) * idv;
+        else if (i == nv - 1) gd = (f1[nv - 1] - f1[nv - 2]) * idv;
+        else gd = (f1[i + 1] - f1[i - 1]) * (0.5 * idv);
+        d1[i] = gd;
       }
     }
     __syncthreads();
-    for (int i = tid; i < nv; i += kThreads) {
-      double gd;
-      if (i == 0) gd = (f1[1] - f1[0]) * idv;
-      else if (i == nv - 1) gd = (f1[nv - 1] - f1[nv - 2]) * idv;
-      else gd = (f1[i + 1] - f1[i - 1]) * (0.5 * idv);
-      d1[i] = gd;
-    }
-    __syncthreads();
-    // ---- ratintn(df, vx - |xi_e|, vx): nv - 2 intervals ----
+    // ---- ratintn(df, vx - |xi_e|, vx): nv - 2 intervals (:372-387) ----
     double psum = 0.0;
-    for (int i = tid; i < nv - 2; i += kThreads) {
-      const double f0 = d1[i], f1v = d1[i + 1];
-      const double g0 = (v0 + i * dv) - xmag, g1 = (v0 + (i + 1) * dv) - xmag;
-      const double fdif = f1v - f0, gdif = g1 - g0, fav = 0.5 * (f1v + f0), gav = 0.5 * (g1 + g0);
-      const double tmp = fav * gdif - gav * fdif;
-      double r;
-      if (fabs(gdif) < 1.0e-4 * fabs(gav)) r = fav / gav + tmp * gdif / (12.0 * gav * gav * gav);
-      else r = fdif / gdif + tmp * log(fabs((gav + 0.5 * gdif) / (gav - 0.5 * gdif))) / (gdif * gdif);
-      psum += r * dv;
+    if (active) {
+      for (int i = gt; i < nv - 2; i += kThreads) {
+        const double f0 = d1[i], f1v = d1[i + 1];
+        const double g0 = (v0 + i * dv) - xmag, g1 = (v0 + (i + 1) * dv) - xmag;
+        const double fdif = f1v - f0, gdif = g1 - g0, fav = 0.5 * (f1v + f0), gav = 0.5 * (g1 + g0);
+        const double tmp = fav * gdif - gav * fdif;
+        double r;
+        if (fabs(gdif) < 1.0e-4 * fabs(gav)) r = fav / gav + tmp * gdif / (12.0 * gav * gav * gav);
+        else r = fdif / gdif + tmp * log(fabs((gav + 0.5 * gdif) / (gav - 0.5 * gdif))) / (gdif * gdif);
+        psum += r * dv;
+      }
     }
-    const double R = block_sum(psum, red);
-    if (tid == 0) {
+    psum = wave_sum(psum);
+    if ((gt & 63) == 0) red[gt >> 6] = psum;
+    __syncthreads();
+    if (active && gt == 0) {
+      const double R = (red[0] + red[1]) + (red[2] + red[3]);
+      const double k2 = sc[3], k = sc[4], wd = sc[5], ws = sc[6], a_e = sc[7], ivTe = sc[8], wL = sc[9], pref = sc[10];
       // jnp.interp(|xi_e|, vx, .): clamps to the end values
       double u = (xmag - v0) * idv;
       int i = (int)u;
@@ -1330,25 +1394,25 @@ __global__ __launch_bounds__(kThreads) void k_form_factor_2d(KStatic S, const do
       t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
       const double fe_vphi = f1[i] + t * (f1[i + 1] - f1[i]);
       const double dfe = d1[i] + t * (d1[i + 1] - d1[i]);
-      const double ike2 = L.a_e / k2;
+      const double ike2 = a_e / k2;
       const double cer = -ike2 * R, cei = kPi * ike2 * dfe;
       double cre = 0.0, cim = 0.0, gsum = 0.0;
       const double vph = wd / k;
 #pragma unroll
       for (int s = 0; s < NI; ++s) {
-        const double xi = vph * L.ixi[s];
+        const double xi = vph * sc[12 + 3 * s];
         double zr, zi, dzr, dzi, gs;
         ion_terms(S.zp, xi, zr, zi, dzr, dzi, gs);   // (one thread per point: the Z' table is read from global memory)
-        const double iki2 = L.a_i[s] / k2;
+        const double iki2 = sc[13 + 3 * s] / k2;
         cre -= 0.5 * iki2 * zr;
         cim -= 0.5 * iki2 * zi;
-        gsum += L.cs[s] * gs;
+        gsum += sc[14 + 3 * s] * gs;
       }
       const double er = 1.0 + cer + cre, ei = cei + cim;
       const double eps2 = er * er + ei * ei, ce2 = cer * cer + cei * cei;
       const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
-      const double Sv = (gsum * ce2 + ci2 * fe_vphi * L.ivTe) / (k * eps2);
-      P[pid] = Sv * (1.0 + 2.0 * wd / L.wL) * L.pref * ws * ws;
+      const double Sv = (gsum * ce2 + ci2 * fe_vphi * ivTe) / (k * eps2);
+      P[pid] = Sv * (1.0 + 2.0 * wd / wL) * pref * ws * ws;
     }
   }
 }

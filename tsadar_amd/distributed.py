@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
+
 
 def init_from_env(backend: str | None = None):
     """torch.distributed initialisation from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
@@ -62,3 +64,34 @@ def allreduce_loss_grad(terms, grad_local, world: int, rank: int, group=None):
     buf[3:].view(P, world, Bl)[:, rank, :] = grad_local
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf[:3], buf[3:]
+
+
+def point_range(n_points: int, world: int, rank: int):
+    """Contiguous slice of the flat (lineout, gradient point, wavelength, angle) list of the 2-D angular path for
+    rank ``rank``: equal chunks of ceil(n / world) points, the last one shorter (form_factor.py:431-447 shards the
+    same list with a NamedSharding)."""
+    chunk = -(-n_points // world)
+    lo = min(rank * chunk, n_points)
+    return lo, min(lo + chunk, n_points), chunk
+
+
+def form_factor_2d_sharded(engine, feature, phys, fe2d, ud_angle, va_angle, world: int, rank: int, group=None):
+    """FormFactor.calc_in_2D over the ranks of a node: f_e and parameters replicated, each rank evaluates its slice of
+    the point list (tsff_form_factor_2d_range), one all-gather of equal (padded) chunks assembles P on every rank.
+    No reduction is involved; the result is bit-identical to the single-rank one."""
+    import torch
+
+    if world == 1:
+        return engine.form_factor_2d(feature, phys, fe2d, ud_angle, va_angle)
+    import torch.distributed as dist
+
+    B = np.asarray(phys).reshape(-1, engine.NP).shape[0] if not hasattr(phys, "shape") else int(phys.reshape(-1, engine.NP).shape[0])
+    shape = (B, int(engine._cfg_struct.num_grad_points), engine.npts, int(engine._cfg_struct.n_angles))
+    n = int(np.prod(shape))
+    lo, hi, chunk = point_range(n, world, rank)
+    full = torch.zeros(chunk * world, dtype=torch.float64, device=engine.device)
+    view = full[:n].view(shape)
+    engine.form_factor_2d(feature, phys, fe2d, ud_angle, va_angle, point_range=(lo, hi), out=view)
+    mine = full[rank * chunk : (rank + 1) * chunk].clone()
+    dist.all_gather_into_tensor(full, mine, group=group)
+    return full[:n].view(shape)

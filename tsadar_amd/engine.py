@@ -306,9 +306,10 @@ class Engine:
         L.check(self.lib, self.h, self.lib.tsff_form_factor(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), B, self._ptr(P)))
         return P
 
-    def form_factor_2d(self, feature, phys, fe2d, ud_angle=0.0, va_angle=0.0):
+    def form_factor_2d(self, feature, phys, fe2d, ud_angle=0.0, va_angle=0.0, point_range=None, out=None):
         """FormFactor.calc_in_2D: phys [B, NP] PHYSICAL parameters, fe2d [nv, nv] (shared) or [B, nv, nv]
-        -> P [B, G, npts, n_angles]."""
+        -> P [B, G, npts, n_angles].  ``point_range = (begin, end)`` evaluates that slice of the flat point list only
+        (the rest of ``out`` / a zero-filled result is untouched): the sharding unit of the multi-GPU path."""
         torch = self.torch
         phys_d = self.dev(phys).reshape(-1, self.NP)
         B = phys_d.shape[0]
@@ -317,10 +318,14 @@ class Engine:
         nv = int(fe_d.shape[-1])
         assert fe_d.shape[-2] == nv and (shared or fe_d.shape[0] == B)
         G, NA = int(self._cfg_struct.num_grad_points), int(self._cfg_struct.n_angles)
-        P = torch.empty((B, G, self.npts, NA), dtype=torch.float64, device=self.device)
+        if out is not None:
+            P = out
+        else:
+            P = (torch.zeros if point_range is not None else torch.empty)((B, G, self.npts, NA), dtype=torch.float64, device=self.device)
+        lo, hi = point_range if point_range is not None else (0, -1)
         self._sync_stream()
-        rc = self.lib.tsff_form_factor_2d(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, int(shared),
-                                          float(ud_angle), float(va_angle), B, self._ptr(P))
+        rc = self.lib.tsff_form_factor_2d_range(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, int(shared),
+                                                float(ud_angle), float(va_angle), B, int(lo), int(hi), self._ptr(P))
         L.check(self.lib, self.h, rc)
         return P
 

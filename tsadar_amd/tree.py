@@ -78,3 +78,35 @@ def combine(a, b) -> ThomsonParams:
 
 def ravel_pytree(diff: DiffParams) -> Tuple[np.ndarray, Callable[[np.ndarray], DiffParams]]:
     return diff.ravel(), diff.like
+
+
+# ---- what the adam loop of the reference needs around vg_loss (loops.py:74-93) -----------------------------
+def tree_map(fn, *diffs: DiffParams) -> DiffParams:
+    """Leaf-wise map over DiffParams of identical structure (jax.tree_util.tree_map for this container)."""
+    return DiffParams(diffs[0].slots, [fn(*vs) for vs in zip(*(d.values for d in diffs))])
+
+
+def apply_updates(diff: DiffParams, updates: DiffParams) -> DiffParams:
+    """eqx.apply_updates / optax.apply_updates."""
+    return tree_map(lambda p, u: p + u, diff, updates)
+
+
+class Adam:
+    """optax.adam(learning_rate) for DiffParams (b1 = 0.9, b2 = 0.999, eps = 1e-8, eps_root = 0, bias-corrected):
+    ``state = opt.init(params)``, ``updates, state = opt.update(grads, state)``."""
+
+    def __init__(self, learning_rate: float, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
+        self.lr, self.b1, self.b2, self.eps = learning_rate, b1, b2, eps
+
+    def init(self, params: DiffParams):
+        z = tree_map(np.zeros_like, params)
+        return (0, z, tree_map(np.zeros_like, params))
+
+    def update(self, grads: DiffParams, state, params=None):
+        count, mu, nu = state
+        count += 1
+        mu = tree_map(lambda m, g: self.b1 * m + (1 - self.b1) * g, mu, grads)
+        nu = tree_map(lambda v, g: self.b2 * v + (1 - self.b2) * g * g, nu, grads)
+        c1, c2 = 1 - self.b1**count, 1 - self.b2**count
+        upd = tree_map(lambda m, v: -self.lr * (m / c1) / (np.sqrt(v / c2) + self.eps), mu, nu)
+        return upd, (count, mu, nu)
