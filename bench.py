@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--free-form", action="store_true",
                     help="variant: explicit per-lineout f_e tables with the gradient w.r.t. f_e itself (Arbitrary1V-style "
                          "free-form distribution, nvx more unknowns per lineout; not the headline metric)")
+    ap.add_argument("--plan", type=int, default=0, help="launch plan (experiments): 0 automatic, 1 never interleave the features")
     args = ap.parse_args()
     variant = args.dlm or args.free_form
 
@@ -164,6 +165,8 @@ def main():
 
     eng = Engine(cfg, sa, activate=True, fe_mode=L.FE_PER_LINEOUT if args.free_form else None)
 
+    if args.plan:
+        eng.set_launch_plan(args.plan)
     # synthetic inputs: each rank draws its own shard (seed offset by rank), data generated on the GPU
     rng = np.random.default_rng(S.SEED + rank)
     truth = S.draw_params(cfg, B, rng, dlm=args.dlm)

@@ -10,6 +10,6 @@ for d in ("gpurun_out/pmc_${tag}_a","gpurun_out/pmc_${tag}_b"):
         rows=list(csv.DictReader(open(f)))
         agg=collections.defaultdict(list)
         for r in rows:
-            if "k_spectrum<1, 1>" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if "k_spectrum<1, 1" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k,v in agg.items(): print(k, len(v), sum(v)/len(v))
 PY

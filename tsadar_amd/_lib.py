@@ -26,6 +26,7 @@ FE_SHARED, FE_PER_LINEOUT, FE_DLM = range(3)
 LOSS_METHODS = {"l2": 0, "l1": 1, "log-cosh": 2, "poisson": 3}
 FEATURE_ELE, FEATURE_ION = 0, 1
 OPT_DENOM_MODE = 1
+OPT_LAUNCH_PLAN = 2
 
 
 def n_params(n_ion: int) -> int:

@@ -59,6 +59,7 @@ struct KCall {
   double* thry[2];
   double* sqdev[2];
   double* lpart;         // [B][3]
+  double* gpart;         // [2][B][NP] per-feature gradient parts (interleaved plan)
   double wts[3];
   int B;
   int denom_mode;        // MODE 1 only: 0 constant denominators (folded into wts), 2: |data| + 1e-10 per sample
@@ -741,14 +742,17 @@ template <int NI, int MODE, int GM = 0, int TPF = kHalf>
 __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCall K, int f0, int nfeat, int flags,
                                                            const uint8_t* __restrict__ gmask, double* __restrict__ grad) {
   // flags bit 0: add to grad instead of overwriting it (second launch of a feature-split call);
-  //       bit 1: k_s cache present in LDS
-  const bool accumulate = flags & 1, use_ks = flags & 2;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  //       bit 1: k_s cache present in LDS;
+  //       bit 2: interleaved plan -- grid 2B, workgroup f B + b evaluates feature f of lineout b and leaves its part of
+  //              the gradient in K.gpart[f][b][:]; k_loss_reduce adds the two parts
+  const bool accumulate = flags & 1, use_ks = flags & 2, interleaved = flags & 4;
+  const int f_il = interleaved ? (int)(blockIdx.x >= (unsigned)K.B) : 0;  // first B workgroups: feature 0, next B: feature 1
+  const int b = interleaved ? (int)blockIdx.x - f_il * K.B : (int)blockIdx.x, tid = threadIdx.x;
   // TPF threads per feature: 256 when the workgroup holds both features, 512 for a one-feature workgroup
   constexpr int NW = TPF / 64;          // wavefronts per feature
   constexpr int BPT = TSFF_NBINS / TPF;  // output bins per thread
   const int half = tid / TPF, ht = tid % TPF, lane = tid & 63, hw = ht >> 6;
-  const int f = f0 + half;  // feature of this group (wavefront-uniform)
+  const int f = interleaved ? f_il : f0 + half;  // feature of this group (wavefront-uniform)
   extern __shared__ __align__(16) unsigned char smem[];
   const Smem m = carve(smem, S, nfeat, GM != 0, use_ks);
   Tables T;
@@ -1099,13 +1103,20 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     double v = gsum[tid] * S.p_scale[tid];
     if (S.p_sig[tid]) { const double sg = sigmoid(xv); v *= sg * (1.0 - sg); }
     v = gmask[tid] ? v : 0.0;
-    grad[(size_t)b * NPk + tid] = accumulate ? grad[(size_t)b * NPk + tid] + v : v;
+    if (interleaved) K.gpart[((size_t)f * K.B + b) * NPk + tid] = v;  // summed over the two features by k_loss_reduce
+    else grad[(size_t)b * NPk + tid] = accumulate ? grad[(size_t)b * NPk + tid] + v : v;
   }
 }
 
-// deterministic reduction of lpart[B][3] -> out[3]; one workgroup, fixed order
-__global__ __launch_bounds__(kThreads) void k_loss_reduce(const double* __restrict__ lpart, int B, double* __restrict__ out) {
+// deterministic reduction of lpart[B][3] -> out[3] by workgroup 0 in a fixed order; with gpart (interleaved plan) every
+// workgroup also adds the two per-feature gradient parts: grad[i] = gpart[0][i] + gpart[1][i], i < n
+__global__ __launch_bounds__(kThreads) void k_loss_reduce(const double* __restrict__ lpart, int B, double* __restrict__ out,
+                                                          const double* __restrict__ gpart, long n, double* __restrict__ grad) {
   __shared__ double red[8];
+  if (gpart) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) grad[i] = gpart[i] + gpart[n + i];
+  }
+  if (blockIdx.x != 0) return;
   double a[3] = {0.0, 0.0, 0.0};
   for (int b = threadIdx.x; b < B; b += kThreads) {
     a[0] += lpart[(size_t)b * 3 + 0]; a[1] += lpart[(size_t)b * 3 + 1]; a[2] += lpart[(size_t)b * 3 + 2];

@@ -463,6 +463,10 @@ class Engine:
         """0: constant denominators (fit loss); 2: |data| + 1e-10 per sample (the reference's Hessian loss)."""
         L.check(self.lib, self.h, self.lib.tsff_set_option(self.h, L.OPT_DENOM_MODE, int(mode)))
 
+    def set_launch_plan(self, plan: int):
+        """0: automatic (one 256-thread workgroup per (lineout, feature) when two fit a CU); 1: never interleave."""
+        L.check(self.lib, self.h, self.lib.tsff_set_option(self.h, L.OPT_LAUNCH_PLAN, int(plan)))
+
     def fp64_fma_peak_tflops(self) -> float:
         """Measured FP64 vector FMA rate of this device (micro-benchmark, TFLOP/s)."""
         v = C.c_double()
