@@ -99,7 +99,9 @@ def cpu_baseline(cfg, B, n_sample):
         }
 
     names = ["Te", "ne", "Ti_1", "Va", "lam", "amp1"]
-    cores = max(1, min(os.cpu_count() or 1, 16, n))
+    # torch's autograd engine initialises the HIP runtime in every process that runs a backward pass (it sizes its
+    # device-thread pool with hipGetDeviceCount), and a GPU box allows few processes on its card at once: 5 workers
+    cores = max(1, min(os.cpu_count() or 1, 5, n))
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores, initializer=_cpu_worker_init) as pool:
         batches = pool.map(_cpu_prepare, [(cfg, sa1, named(truth.X, b), S.SEED + 1 + b) for b in range(n)], chunksize=4)
@@ -123,7 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="lineouts per GPU")
     ap.add_argument("--ppp", type=int, default=1, help="points per pixel (1 -> 1024 wavelength points per feature)")
-    ap.add_argument("--cpu-sample", type=int, default=512, help="lineouts of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="lineouts of the CPU baseline (0 = skip)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: forward-only (not the headline metric)")
     ap.add_argument("--dlm", action="store_true",
                     help="variant: the reference's canonical active set {Te, ne, m, amp1, amp2, lam} with a per-lineout "
@@ -246,9 +248,12 @@ def main():
     kavg_s = float(np.mean(ktimes)) * 1e-3 if ktimes.size else float("nan")
     # HBM bytes per launch from the PMC passes of this round (rocprofv3 --pmc cannot run inside bench.py):
     # profiles/r01_traffic.json, produced by scripts/profile_round.sh on the same workload
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tfile) and not args.forward_only and not variant:
+    traffic, tfile = None, None
+    import glob
+
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))  # the latest round's file last
+    if cands and not args.forward_only and not variant:
+        tfile = cands[-1]
         tj = json.load(open(tfile))
         if tj.get("B") == B and tj.get("ppp") == args.ppp:
             traffic = tj["hbm_bytes_per_launch"]
@@ -290,9 +295,10 @@ def main():
             "unit": "GB/s",
             "frac": achieved * 1e9 / HBM_PEAK,
             "traffic": traffic,
-            "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
+            "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % (os.path.basename(tfile) if tfile else "-"),
             "algorithmic_bytes_per_launch": B * abytes,
-            "kernel": "k_spectrum<1,1>" if not args.forward_only else "k_spectrum<1,0>",
+            "kernel": ("k_spectrum<1,0,0,256>" if args.forward_only else "k_spectrum<1,1,GM,256> (fused features)" if variant
+                       else "k_spectrum<1,1,0,256> (one launch of 2B 256-thread workgroups)"),
             "kernel_avg_ms": kavg_s * 1e3,
             "algorithmic_bytes_per_spectrum": abytes,
             "note": "the path is FP64-VALU bound (SURVEY.md 8d); see roofline_fp64",
