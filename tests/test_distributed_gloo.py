@@ -138,5 +138,5 @@ def test_shard_bounds_and_single_rank_passthrough():
         D.shard_bounds(10, 4, 0)
     t = torch.arange(3, dtype=torch.float64)
     g = torch.arange(12, dtype=torch.float64).reshape(3, 4)
-    tt, gg = D.allreduce_loss_grad(t, g, 1, 0)
+    tt, gg = D.exchange_loss_grad(t, g, 1, 0)
     assert torch.equal(tt, t) and torch.equal(gg, g.reshape(-1))
