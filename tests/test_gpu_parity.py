@@ -862,3 +862,70 @@ def test_two_rank_sharded_form_factor_2d(torch_mod, tmp_path):
     np.testing.assert_array_equal(p0[0], p0[1])
     np.testing.assert_array_equal(p1[0], p1[1])
     np.testing.assert_array_equal(p0[0], p1[0])
+
+
+def _random_deck(seed):
+    """A randomly configured deck: ion species, gradient points, points per pixel, velocity grid, wavelength windows,
+    notch filter, IRF widths, fit ranges, loss functional, drifts -- everything the static configuration can vary."""
+    rng = np.random.default_rng(1000 + seed)
+    n_ion = int(rng.integers(1, 3))
+    active = ["Te", "ne", "Ti", "lam", "amp1", "amp2", "amp3", "Va", "ud"]
+    if rng.random() < 0.5:
+        active += ["Z"]
+    G = int(rng.integers(1, 4))
+    if G > 1:
+        active += ["Te_gradient", "ne_gradient"]
+    cfg = decks.deck_fit(points_per_pixel=int(rng.integers(1, 3)), nvx=int(rng.choice([64, 96, 128, 200])),
+                         m=float(rng.uniform(2.0, 4.5)), active=tuple(active), n_ion=n_ion)
+    g = cfg["parameters"]["general"]
+    g["Te_gradient"].update(val=float(rng.uniform(0, 8)), num_grad_points=G)
+    g["ne_gradient"].update(val=float(rng.uniform(0, 12)), num_grad_points=G)
+    g["ud"]["val"] = float(rng.uniform(-2, 2))
+    g["Va"]["val"] = float(rng.uniform(-3, 3))
+    r = cfg["data"]["fit_rng"]
+    r["forward_epw_start"], r["forward_epw_end"] = float(rng.uniform(380, 430)), float(rng.uniform(640, 720))
+    r["blue_min"], r["blue_max"] = float(rng.uniform(440, 470)), float(rng.uniform(495, 515))
+    r["red_min"], r["red_max"] = float(rng.uniform(535, 560)), float(rng.uniform(600, 630))
+    other = cfg["other"]
+    other["iawfilter"] = [int(rng.integers(0, 2)), float(rng.uniform(2, 5)), float(rng.uniform(10, 30)), float(rng.uniform(524, 530))]
+    other["PhysParams"]["widIRF"] = {"spect_stddev_ele": float(rng.uniform(0.6, 2.0)), "spect_stddev_ion": float(rng.uniform(0.008, 0.03))}
+    ext = other["extraoptions"]
+    ext["fit_EPWb"], ext["fit_EPWr"] = bool(rng.random() < 0.8), True
+    cfg["data"]["ion_loss_scale"] = float(rng.uniform(0.3, 3.0))
+    cfg["data"]["ele_lam_shift"] = float(rng.uniform(-0.5, 0.5))
+    cfg["optimizer"]["loss_method"] = str(rng.choice(["l2", "l1", "log-cosh", "poisson"]))
+    cfg["optimizer"]["y_norm"] = bool(rng.random() < 0.7)
+    if n_ion == 2:
+        cfg["parameters"]["ion-2"]["Ti"]["same"] = bool(rng.random() < 0.5)
+    return decks.finish(cfg), n_ion
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_decks_forward_loss_gradient(torch_mod, seed):
+    """Randomly configured decks (species, gradient points, points per pixel, nvx, windows, notch filter, IRF widths, fit
+    ranges, loss functional, noise arrays): spectra vs the NumPy oracle, loss and gradient vs autodiff of its twin."""
+    from oracle import tsadar_oracle_torch as ot
+
+    cfg, n_ion = _random_deck(seed)
+    B = 2
+    sa = util.sa_fit(B)
+    batch = util.synthetic_batch(cfg, sa, B, seed=300 + seed)
+    rng = np.random.default_rng(seed)
+    batch["noise_e"] = 0.02 * rng.random((B, 1024))
+    batch["noise_i"] = 0.02 * rng.random((B, 1024))
+    normed = util.random_lineouts(cfg, B, seed=400 + seed, ranges=dict(ud=(-2, 2), Ti_2=(0.05, 0.5)))
+    i_norm, e_norm = orc.loss_norms(cfg, batch)
+    eng = _engine(cfg, sa)
+    X = util.normed_to_matrix(normed, n_ion)
+    Eo, Io, _, _ = orc.ts_diag(cfg, sa, normed, batch)
+    E, I = eng.forward(X, batch["e_amps"], batch["i_amps"], batch["noise_e"], batch["noise_i"])
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-8 and util.rel_err(I.cpu().numpy(), Io) < 1e-8, cfg["optimizer"]
+    names = [k for k in normed if eng.slots.active[util.slot_of(k)]]
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    terms, grad, _, _ = eng.loss_grad(X, batch, w, eng.slots.active.astype(np.uint8))
+    val, ref, _, _ = ot.value_and_grad(cfg, sa, normed, batch, i_norm, e_norm, names)
+    assert abs(float(np.dot(terms.cpu().numpy(), w)) - val) < 1e-9 * abs(val), (cfg["optimizer"]["loss_method"], val)
+    Gd = util.matrix_to_named(grad.cpu().numpy(), names)
+    scale = max(np.max(np.abs(v)) for v in ref.values())
+    for k in names:
+        assert np.max(np.abs(Gd[k] - ref[k])) / scale < 1e-6, (k, cfg["optimizer"]["loss_method"], Gd[k], ref[k])
