@@ -8,7 +8,7 @@ spectrum, batch 4096 per GPU, P = 6 free parameters (BASELINE.json metric, confi
 
 A step = one evaluation of loss + gradient (tsff_loss_grad) over this rank's 4096 lineouts, with the
 inputs (params, data, amplitudes) already resident in HBM, plus -- for N > 1 -- the single RCCL
-all-gather of [3 loss sums | gradient block] (weak scaling: 4096 lineouts per GPU).  Rank 0 prints ONE JSON
+all-reduce of [3 loss sums | gradient] (weak scaling: 4096 lineouts per GPU).  Rank 0 prints ONE JSON
 line.  The oracle is used only for the ``cpu_baseline`` leg (rank 0, N = 1).
 """
 from __future__ import annotations
@@ -201,7 +201,7 @@ def main():
         else:
             eng.loss_grad(X, batch, w, gmask, out=(terms, grad))
             g = grad[:, act].t().contiguous()
-        return D.exchange_loss_grad(terms, g, world, rank)
+        return D.allreduce_loss_grad(terms, g, world, rank)
 
     def fence():
         if world > 1:
@@ -286,7 +286,7 @@ def main():
             "n_lambda": 1024 * args.ppp,
             "n_angles": 10,
             "free_params": P,
-            "parallelism": f"lineout-sharded x{world}, one all-gather of [3 + B*P] f64 per rank and step" if world > 1 else "single GPU",
+            "parallelism": f"lineout-sharded x{world}, one all-reduce of [3 + B*P] f64 per step" if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "hbm",

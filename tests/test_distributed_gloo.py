@@ -107,6 +107,12 @@ def _rank_main(rank, world, port, B, out):
     static_l = tree.StaticParams(tp_local)
     value, flat = lf.vg_loss(x0, static_l, local)
     np.save(os.path.join(out, f"flat_{rank}.npy"), np.concatenate([[value], flat]))
+    # the all-gather alternative returns the same tensors as the all-reduce
+    t = torch.arange(3, dtype=torch.float64) + rank
+    g = torch.arange(10, dtype=torch.float64).reshape(2, 5) * (rank + 1)
+    ta, ga = D.allreduce_loss_grad(t, g, world, rank)
+    tg, gg = D.allgather_loss_grad(t, g, world, rank)
+    assert torch.equal(ta, tg) and torch.equal(ga, gg)
     dist.destroy_process_group()
 
 
@@ -138,5 +144,5 @@ def test_shard_bounds_and_single_rank_passthrough():
         D.shard_bounds(10, 4, 0)
     t = torch.arange(3, dtype=torch.float64)
     g = torch.arange(12, dtype=torch.float64).reshape(3, 4)
-    tt, gg = D.exchange_loss_grad(t, g, 1, 0)
+    tt, gg = D.allreduce_loss_grad(t, g, 1, 0)
     assert torch.equal(tt, t) and torch.equal(gg, g.reshape(-1))

@@ -1,7 +1,7 @@
 """Drop-in for ``tsadar.inverse.loss_function.LossFunction`` (reference
 inverse/loss_function.py:22-418): ``vg_loss`` / ``loss`` / ``array_loss`` with the reference
 signatures, evaluated by the HIP engine (forward + hand-written adjoint), optionally sharded over
-the GPUs of one node with a single RCCL all-gather of [loss sums | gradient block] per evaluation.
+the GPUs of one node with a single RCCL all-reduce of [loss sums | gradient] per evaluation.
 """
 from __future__ import annotations
 
@@ -65,7 +65,7 @@ class LossFunction:
 
     def _evaluate(self, ts_params: ThomsonParams, batch, want_spectra=False):
         """Local shard: -> (value, grad[B_local, NP] numpy, ThryE, ThryI).  In distributed mode the
-        value is the global loss (after the all-gather) and grad the LOCAL block."""
+        value is the global loss (after the all-reduce) and grad the LOCAL block."""
         import torch
 
         eng = self.ts_diag.engine(ts_params.activate)
@@ -107,7 +107,7 @@ class LossFunction:
         gact = grad[:, act].t().contiguous()  # [P, B_local], ravel order
         if getattr(self, "_gfe", None) is not None and ts_params.slots.fval_active:
             gact = torch.cat([gact, self._gfe.t().contiguous()])  # nvx more rows: d loss / d fe, chained on the host
-        terms, gflat = D.exchange_loss_grad(terms, gact, world, rank, self.pg)  # the one collective per step
+        terms, gflat = D.allreduce_loss_grad(terms, gact, world, rank, self.pg)  # the one collective per step
         host = torch.cat([terms, gflat]).cpu().numpy()  # single D2H copy: 3 + P*B doubles
         value = float(np.dot(host[:3], w))
         flat = host[3:]
