@@ -929,3 +929,61 @@ def test_random_decks_forward_loss_gradient(torch_mod, seed):
     scale = max(np.max(np.abs(v)) for v in ref.values())
     for k in names:
         assert np.max(np.abs(Gd[k] - ref[k])) / scale < 1e-6, (k, cfg["optimizer"]["loss_method"], Gd[k], ref[k])
+
+
+def test_angular_vg_loss_finite_difference(torch_mod):
+    """LossFunction for spectype angular_full: value = the reference's calc_ei_error on the ARTS image (oracle chain end
+    to end for a 1-D DLM f_e), gradient = central differences over full GPU forwards (no adjoint of the angular model
+    yet) vs central differences of the oracle; an L-BFGS-B run recovers a perturbed temperature."""
+    from scipy.optimize import minimize
+
+    from tsadar_amd import ThomsonParams, tree
+    from tsadar_amd.loss_function import LossFunction
+
+    cfg = decks.deck_angular(1, 64, (128, 256), 10, 110)
+    for k in ("amp1", "amp2", "lam"):
+        cfg["parameters"]["general"][k]["active"] = False
+    cfg["parameters"]["electron"]["fe"]["active"] = False
+    sa = _angular_sa(cfg)
+    vx = orc.velocity_grid(64)
+
+    def oracle_image(normed, e_amps):
+        phys = orc.physical_params(cfg["parameters"], normed, True)
+        p = orc.lineout_params(phys, 0, 1)
+        Po, lam_cm = orc.form_factor(cfg["other"]["lamrangE"], 1024, 0.0, sa["sa"], 1, p, vx, orc.dlm_fe(float(p["m"]), 64))
+        return orc.ats_spectrum(cfg, sa["weights"], sa["angAxis"], Po, np.squeeze(lam_cm) * 1e7, 256, e_amps, p)
+
+    truth = orc.init_normed_params(cfg["parameters"], 1, True)
+    truth["Te"] = truth["Te"] - 0.4
+    truth["ne"] = truth["ne"] + 0.3
+    data, lam = oracle_image(truth, np.ones((100, 1)))
+    batch = dict(e_data=data, i_data=np.zeros((100, 256)), e_amps=np.ones((100, 1)), i_amps=np.zeros(100),
+                 noise_e=np.array([0.0]), noise_i=np.array([0.0]))
+    loss_fn = LossFunction(cfg, sa, batch)
+    tp = ThomsonParams(cfg["parameters"], 1, batch=False, activate=True)
+    spec = tree.get_filter_spec(cfg["parameters"], tp)
+    assert [n for n, _ in spec] == [("electron", "Te"), ("electron", "ne")]
+    diff, static = tree.partition(tp, spec)
+    x0, loss_fn.unravel_weights = tree.ravel_pytree(diff)
+    val, g = loss_fn.vg_loss(x0, static, batch)
+
+    def oracle_loss(x):
+        n = orc.init_normed_params(cfg["parameters"], 1, True)
+        n["Te"], n["ne"] = np.array([x[0]]), np.array([x[1]])
+        E, lam_o = oracle_image(n, batch["e_amps"])
+        err = np.square(data - E) / loss_fn.e_norm**2
+        r = cfg["data"]["fit_rng"]
+        blue = (lam_o > r["blue_min"]) & (lam_o < r["blue_max"])
+        red = (lam_o > r["red_min"]) & (lam_o < r["red_max"])
+        return 0.5 * (np.mean(err[:, blue]) + np.mean(err[:, red]))
+
+    vo = oracle_loss(x0)
+    assert abs(val - vo) < 1e-7 * abs(vo), (val, vo)
+    h = 1e-5
+    go = np.array([(oracle_loss(x0 + h * e) - oracle_loss(x0 - h * e)) / (2 * h) for e in np.eye(2)])
+    assert np.max(np.abs(g - go)) < 1e-4 * np.max(np.abs(go)), (g, go)
+    res = minimize(loss_fn.vg_loss, x0, args=(static, batch), method="L-BFGS-B", jac=True,
+                   options={"maxiter": 60, "ftol": 1e-15, "gtol": 1e-12})
+    # (the image loss has kinks -- table cells, row arg-max -- where the line search of L-BFGS-B stalls close to the truth)
+    assert res.fun < 0.03 * val, (res.x, res.fun, val, res.nit)
+    np.testing.assert_allclose(res.x, [truth["Te"][0], truth["ne"][0]], atol=4e-2)

@@ -143,6 +143,29 @@ class SphericalHarmonics:
                 else:
                     raise NotImplementedError(f"Unknown flm_type: {p.get('flm_type')}")
 
+    # trainable leaves in the reference's pytree order (get_distribution_filter_spec, base.py:484-523): the radial
+    # functions of every harmonic (log_10_LT for Mora-Yahi; flm_sign then flm_mag for the free radial functions), then
+    # normed_m
+    def get_params(self) -> np.ndarray:
+        parts = []
+        for key in sorted(self.flm):
+            prm = self.flm[key]
+            parts += [np.atleast_1d(prm["log_10_LT"])] if self.flm_type == "mora-yahi" else [prm["flm_sign"], prm["flm_mag"]]
+        return np.concatenate(parts + [np.atleast_1d(self.normed_m)]).astype(np.float64)
+
+    def set_params(self, vec) -> None:
+        vec = np.asarray(vec, dtype=np.float64).ravel()
+        o = 0
+        for key in sorted(self.flm):
+            prm = self.flm[key]
+            if self.flm_type == "mora-yahi":
+                prm["log_10_LT"] = float(vec[o]); o += 1
+            else:
+                n = self.vr.size
+                prm["flm_sign"] = vec[o : o + n].copy(); o += n
+                prm["flm_mag"] = vec[o : o + n].copy(); o += n
+        self.normed_m = float(vec[o])
+
     def get_unnormed_m(self) -> float:
         return 1.0 / (1.0 + np.exp(-self.normed_m)) * self.m_scale + self.m_shift
 

@@ -32,9 +32,10 @@ class LossFunction:
         self.multiplex_ang = isinstance(cfg["data"].get("shotnum"), list)
         if self.multiplex_ang:
             raise NotImplementedError("multiplexed angular fits are outside the 1-D form-factor path")
-        if "angular" in cfg["other"]["extraoptions"]["spectype"]:
-            raise NotImplementedError("the gradient of the angular (ARTS) model is not built: forward only "
-                                      "(ThomsonScatteringDiagnostic)")
+        self.angular = "angular" in cfg["other"]["extraoptions"]["spectype"]
+        if self.angular and distributed:
+            raise NotImplementedError("angular fits evaluate one plasma condition: nothing to shard over lineouts")
+        self.fd_step = 1e-5  # normalised units; central differences of the angular model (see _vg_angular)
         self.ts_diag = ThomsonScatteringDiagnostic(cfg, scattering_angles=scattering_angles)
         self.distributed = distributed
         self.pg = process_group
@@ -86,6 +87,55 @@ class LossFunction:
         terms, grad, E, I = eng.loss_grad(X, db, w, ts_params.grad_mask(), want_spectra=want_spectra)
         return eng, w, terms, grad, E, I
 
+    # ---- angular (ARTS) decks ------------------------------------------------------------------
+    def _angular_value(self, ts_params: ThomsonParams, batch):
+        """calc_loss / calc_ei_error for one ARTS image (loss_function.py:190-267, 269-341, 364-373): the electron
+        feature only (ARTS measures no ion feature), masks on the resolution-unit wavelength axis, nanmean over the
+        whole image, (blue + red) / 2."""
+        E, _, lamE, _ = self.ts_diag(ts_params, batch)
+        d = np.asarray(batch["e_data"], dtype=np.float64)
+        method = self.cfg["optimizer"]["loss_method"]
+        un = self.e_norm**2
+        if method == "l1":
+            err = np.abs(d - E) / un
+        elif method == "l2":
+            err = np.square(d - E) / un
+        elif method == "log-cosh":
+            err = np.log(np.cosh(d - E))
+        else:
+            err = E - d * np.log(E)
+        ext, r = self.cfg["other"]["extraoptions"], self.cfg["data"]["fit_rng"]
+        e_error = 0.0
+        if ext["fit_EPWb"]:
+            e_error += float(np.mean(err[:, (lamE > r["blue_min"]) & (lamE < r["blue_max"])]))
+        if ext["fit_EPWr"]:
+            e_error += float(np.mean(err[:, (lamE > r["red_min"]) & (lamE < r["red_max"])]))
+            if ext["fit_EPWb"]:
+                e_error *= 0.5
+        return e_error, E
+
+    def _vg_angular(self, diff_weights, static_weights, batch):
+        """Value and gradient of the angular model.  The reference differentiates its JAX model; the MI355X path has no
+        adjoint of the 2-D form factor yet, so the gradient is a central difference over the trainable scalar leaves
+        (2 P full forward evaluations of the image: P ~ 6, 23 ms each at the ARTS size), step ``fd_step`` in
+        normalised units.  Accuracy is that of the difference quotient (~1e-6 relative), not of autodiff."""
+        ts_params = tree.combine(static_weights, diff_weights)
+        value, E = self._angular_value(ts_params, batch)
+        grads = []
+        for k, ((name, s), v) in enumerate(zip(diff_weights.slots, diff_weights.values)):
+            if s == tree.FVAL_SLOT:
+                raise NotImplementedError("free-form distribution functions are not fitted through finite differences")
+            g = np.zeros_like(v)
+            for idx in np.ndindex(v.shape):
+                vals = []
+                for sgn in (+1.0, -1.0):
+                    pert = [u.copy() for u in diff_weights.values]
+                    pert[k][idx] += sgn * self.fd_step
+                    vals.append(self._angular_value(tree.combine(static_weights, tree.DiffParams(diff_weights.slots, pert)), batch)[0])
+                g[idx] = (vals[0] - vals[1]) / (2 * self.fd_step)
+            grads.append(g)
+        return value, E, ts_params, tree.DiffParams(diff_weights.slots, grads)
+
     # ---- reference API --------------------------------------------------------------------------
     def vg_loss(self, diff_weights, static_weights, batch: Dict):
         """loss_function.py:128-168.  l-bfgs-b: (float value, flat float64 gradient); otherwise
@@ -93,6 +143,13 @@ class LossFunction:
         import torch
 
         lbfgs = self.cfg["optimizer"]["method"] == "l-bfgs-b"
+        if self.angular:
+            if lbfgs:
+                diff_weights = self.unravel_weights(np.asarray(diff_weights, dtype=np.float64))
+            value, E, ts_params, grad = self._vg_angular(diff_weights, static_weights, batch)
+            if lbfgs:
+                return value, grad.ravel()
+            return (value, [E, ts_params()]), grad
         world, rank = self._world()
         if lbfgs:
             diff_weights = self.unravel_weights(np.asarray(diff_weights, dtype=np.float64))
@@ -138,6 +195,9 @@ class LossFunction:
 
     def loss(self, weights, batch: Dict):
         """loss_function.py:344-362."""
+        if self.angular and self.cfg["optimizer"]["method"] != "l-bfgs-b":
+            value, E = self._angular_value(weights, batch)
+            return value, [E, weights()]
         if self.cfg["optimizer"]["method"] == "l-bfgs-b":
             raise NotImplementedError("loss() with flat weights needs unravel_pytree, which the reference never sets "
                                       "(loss_function.py:357); use vg_loss")

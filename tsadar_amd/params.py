@@ -72,6 +72,8 @@ class SlotMap:
         # free-form 1-D distribution (Arbitrary1V): nvx trainable values per lineout, raveled right after (Te, ne)
         self.has_fval = self.fe_type == "arbitrary" and int(fe.get("dim", 1)) == 1
         self.fval_active = self.has_fval and bool(fe.get("active", False))
+        # 2-D generator with a few trainable scalars (SphericalHarmonics): one leaf [1, n] at the same position
+        self.gen2d_active = "sph" in self.fe_type and int(fe.get("dim", 1)) == 2 and bool(fe.get("active", False))
         self.n_electron_leaves = len(self.leaves)
         for i, sp in enumerate(self.species):
             ic = param_cfg[sp]
@@ -177,6 +179,8 @@ class ThomsonParams:
         other.X = self.X.copy()
         if self.fval is not None:
             other.fval = self.fval.copy()
+        if getattr(self, "sph", None) is not None:
+            other.sph = copy.deepcopy(self.sph)
         return other
 
     # ---- scipy-facing: the reference's ravel_pytree(diff_params) ordering -----------------------

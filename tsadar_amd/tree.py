@@ -14,6 +14,7 @@ from .params import ThomsonParams
 
 
 FVAL_SLOT = -1  # pseudo-slot of the free-form distribution-function leaf (Arbitrary1V.fval, [B, nvx])
+GEN2D_SLOT = -2  # pseudo-slot of the trainable scalars of a 2-D generator (SphericalHarmonics), [1, n]
 
 
 class DiffParams:
@@ -54,6 +55,8 @@ def get_filter_spec(cfg_params, ts_params: ThomsonParams):
     for k, (name, s) in enumerate(sm.leaves):
         if k == sm.n_electron_leaves and sm.fval_active:
             spec.append((("electron", "fval"), FVAL_SLOT))
+        if k == sm.n_electron_leaves and sm.gen2d_active:
+            spec.append((("electron", "fe"), GEN2D_SLOT))
         if sm.active[s]:
             spec.append((name, s))
     return spec
@@ -61,7 +64,8 @@ def get_filter_spec(cfg_params, ts_params: ThomsonParams):
 
 def partition(ts_params: ThomsonParams, filter_spec=None) -> Tuple[DiffParams, StaticParams]:
     spec = filter_spec if filter_spec is not None else get_filter_spec(None, ts_params)
-    vals = [ts_params.fval.copy() if s == FVAL_SLOT else ts_params.X[:, s].copy() for _, s in spec]
+    vals = [ts_params.fval.copy() if s == FVAL_SLOT else ts_params.sph.get_params()[None, :] if s == GEN2D_SLOT
+            else ts_params.X[:, s].copy() for _, s in spec]
     return DiffParams(list(spec), vals), StaticParams(ts_params)
 
 
@@ -71,6 +75,8 @@ def combine(a, b) -> ThomsonParams:
     for (_, s), v in zip(diff.slots, diff.values):
         if s == FVAL_SLOT:
             out.fval = np.array(v, dtype=np.float64)
+        elif s == GEN2D_SLOT:
+            out.sph.set_params(v)
         else:
             out.X[:, s] = v
     return out
