@@ -143,7 +143,7 @@ class LossFunction:
         import torch
 
         lbfgs = self.cfg["optimizer"]["method"] == "l-bfgs-b"
-        if self.angular:
+        if getattr(self, "angular", False):
             if lbfgs:
                 diff_weights = self.unravel_weights(np.asarray(diff_weights, dtype=np.float64))
             value, E, ts_params, grad = self._vg_angular(diff_weights, static_weights, batch)
@@ -195,7 +195,7 @@ class LossFunction:
 
     def loss(self, weights, batch: Dict):
         """loss_function.py:344-362."""
-        if self.angular and self.cfg["optimizer"]["method"] != "l-bfgs-b":
+        if getattr(self, "angular", False) and self.cfg["optimizer"]["method"] != "l-bfgs-b":
             value, E = self._angular_value(weights, batch)
             return value, [E, weights()]
         if self.cfg["optimizer"]["method"] == "l-bfgs-b":
