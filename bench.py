@@ -36,47 +36,13 @@ def algorithmic_bytes(NP: int, with_noise: bool) -> int:
     return rd + wr
 
 
-def _cpu_worker_init():
-    import torch
-
-    torch.set_num_threads(1)
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import tsadar_oracle_torch  # noqa: F401  (import cost outside the timed region)
-
-
-def _cpu_prepare(args):
-    """(untimed) synthetic 'measured' data of one lineout: oracle forward at the truth parameters + 1 % noise."""
-    cfg, sa1, truth, seed = args
-    from oracle import tsadar_oracle as orc
-
-    unit = dict(e_amps=np.ones(1), i_amps=np.ones(1), noise_e=np.zeros((1, 1024)), noise_i=np.zeros((1, 1024)))
-    E, I, lE, lI = orc.ts_diag(cfg, sa1, truth, unit)
-    nrng = np.random.default_rng(seed)
-    E = E * (1 + 0.01 * nrng.standard_normal(E.shape))
-    I = I * (1 + 0.01 * nrng.standard_normal(I.shape))
-    iaw, blue, red = orc.fit_masks(cfg, lE, lI)
-    return dict(e_data=E, i_data=I, e_amps=np.array([E[0][blue[0] | red[0]].max()]), i_amps=np.array([I[0][iaw[0]].max()]),
-                noise_e=np.zeros((1, 1024)), noise_i=np.zeros((1, 1024)))
-
-
-def _cpu_worker(args):
-    cfg, sa, normed, batch, names = args
-    from oracle import tsadar_oracle_torch as ot
-
-    val, g, _, _ = ot.value_and_grad(cfg, sa, normed, batch, float(batch["i_data"].max()), float(batch["e_data"].max()), names)
-    return val
-
-
 def cpu_baseline(cfg, B, n_sample):
-    """Oracle (CPU restatement of the reference algorithm; torch float64 autograd stands in for the
-    reference's JAX autodiff) on the first ``n_sample`` lineouts of the same seeded draw, one lineout
-    per task, spread over the host cores with a process pool.  Runs BEFORE this process touches the
-    GPU (no fork after HIP initialisation).  Returns the ``cpu_baseline`` object."""
-    import multiprocessing as mp
-
+    """The oracle on the host cores: oracle/c/tsadar_oracle.cpp (C++/OpenMP restatement of the reference algorithm,
+    loss + gradient by forward-mode dual numbers, pinned to the reference's golden vector in tests/test_oracle_c.py) on
+    the first ``n_sample`` lineouts of the same seeded draw.  Runs before this process touches the GPU.  Returns the
+    ``cpu_baseline`` object."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from tsadar_amd import _lib as L
+    from oracle import c_oracle as co
     from tsadar_amd import synthetic as S
     from tsadar_amd.calibration import sa_lookup
 
@@ -86,35 +52,26 @@ def cpu_baseline(cfg, B, n_sample):
     rng.integers(1 << 31)  # the draw make_batch() consumes on the GPU leg
     guess = S.draw_params(cfg, B, rng)
     p9 = sa_lookup("P9")
-    sa1 = dict(sa=p9["sa"], weights=p9["weights"] * np.ones([1, 10]))
-
-    def named(X, b):
-        return {
-            "Te": X[b:b + 1, L.P_TE], "ne": X[b:b + 1, L.P_NE], "m": X[b:b + 1, L.P_M],
-            "Ti_1": X[b:b + 1, L.P_ION0 + L.ION_TI], "Z_1": X[b:b + 1, L.P_ION0 + L.ION_Z],
-            "A_1": X[b:b + 1, L.P_ION0 + L.ION_A], "fract_1": X[b:b + 1, L.P_ION0 + L.ION_FRACT],
-            "lam": X[b:b + 1, L.P_LAM], "amp1": X[b:b + 1, L.P_AMP1], "amp2": X[b:b + 1, L.P_AMP2],
-            "amp3": X[b:b + 1, L.P_AMP3], "ne_gradient": X[b:b + 1, L.P_NE_GRADIENT],
-            "Te_gradient": X[b:b + 1, L.P_TE_GRADIENT], "ud": X[b:b + 1, L.P_UD], "Va": X[b:b + 1, L.P_VA],
-        }
-
-    names = ["Te", "ne", "Ti_1", "Va", "lam", "amp1"]
-    # torch's autograd engine initialises the HIP runtime in every process that runs a backward pass (it sizes its
-    # device-thread pool with hipGetDeviceCount), and a GPU box allows few processes on its card at once: 5 workers
-    cores = max(1, min(os.cpu_count() or 1, 5, n))
-    ctx = mp.get_context("spawn")
-    with ctx.Pool(cores, initializer=_cpu_worker_init) as pool:
-        batches = pool.map(_cpu_prepare, [(cfg, sa1, named(truth.X, b), S.SEED + 1 + b) for b in range(n)], chunksize=4)
-        tasks = [(cfg, sa1, named(guess.X, b), batches[b], names) for b in range(n)]
-        pool.map(_cpu_worker, tasks[:cores])  # warm-up: imports, W-table cache, allocator
-        t0 = time.perf_counter()
-        pool.map(_cpu_worker, tasks, chunksize=4)
-        dt = time.perf_counter() - t0
+    sa = dict(sa=p9["sa"], weights=p9["weights"] * np.ones([n, 10]))
+    cores = max(1, min(os.cpu_count() or 1, co.max_threads(), 16))
+    ones = dict(e_amps=np.ones(n), i_amps=np.ones(n))
+    # (untimed) synthetic 'measured' data: oracle forward at the truth parameters + 1 % noise, amplitudes = row maxima
+    _, _, E, I = co.loss_grad(cfg, sa, truth.X[:n], ones, nthreads=cores)
+    nrng = np.random.default_rng(S.SEED + 1)
+    E = E * (1 + 0.01 * nrng.standard_normal(E.shape))
+    I = I * (1 + 0.01 * nrng.standard_normal(I.shape))
+    batch = dict(e_data=E, i_data=I, e_amps=E.max(axis=1), i_amps=I.max(axis=1))
+    w = np.array([1.0 / n, 0.5 / n, 0.5 / n])
+    gm = guess.grad_mask()
+    co.loss_grad(cfg, sa, guess.X[:cores], {k: v[:cores] for k, v in batch.items()}, w=w, gmask=gm, nthreads=cores, want_spectra=False)
+    t0 = time.perf_counter()
+    co.loss_grad(cfg, sa, guess.X[:n], batch, w=w, gmask=gm, nthreads=cores, want_spectra=False)
+    dt = time.perf_counter() - t0
     return {
         "value": n / dt, "unit": "spectra/s", "cores": cores, "kind": "port",
-        "sample": (f"first {n} of the {B} lineouts (same seeded parameter draws), loss+grad of one EPW+IAW spectrum each by "
-                   f"torch-f64 reverse-mode autodiff of the oracle (CPU restatement of the reference algorithm, W table cached), "
-                   f"{cores} processes x 1 thread, {dt:.1f} s wall = {dt * cores:.0f} core-seconds"),
+        "sample": (f"first {n} of the {B} lineouts (same seeded parameter draws), loss+grad of one EPW+IAW spectrum each by the "
+                   f"C++/OpenMP oracle (restatement of the reference algorithm, forward-mode dual numbers for the 6 free "
+                   f"parameters, W table built once), {cores} threads, {dt:.1f} s wall = {dt * cores:.0f} core-seconds"),
     }
 
 

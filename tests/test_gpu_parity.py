@@ -987,3 +987,33 @@ def test_angular_vg_loss_finite_difference(torch_mod):
     # (the image loss has kinks -- table cells, row arg-max -- where the line search of L-BFGS-B stalls close to the truth)
     assert res.fun < 0.03 * val, (res.x, res.fun, val, res.nit)
     np.testing.assert_allclose(res.x, [truth["Te"][0], truth["ne"][0]], atol=4e-2)
+
+
+def test_full_batch_against_cpp_oracle(torch_mod):
+    """256 lineouts (BASELINE config 2's batch) checked one by one -- spectra, loss sums and all six gradient columns --
+    against the C++/OpenMP oracle (forward-mode dual numbers, pinned to the reference golden vector in
+    tests/test_oracle_c.py): no sampling, every lineout of the batch."""
+    from oracle import c_oracle as co
+    from tsadar_amd import synthetic as S
+
+    B = 256
+    cfg = S.baseline_deck(batch_size=B)
+    sa = util.sa_fit(B)
+    eng = _engine(cfg, sa)
+    rng = np.random.default_rng(S.SEED)
+    truth = S.draw_params(cfg, B, rng)
+    batch = S.make_batch(eng, truth, rng)
+    guess = S.draw_params(cfg, B, rng)
+    X = guess.to_matrix()
+    hb = {k: (v.cpu().numpy() if v is not None else None) for k, v in batch.items()}
+    w = eng.loss_weights(B, float(hb["i_data"].max()), float(hb["e_data"].max()), cfg["data"]["ion_loss_scale"])
+    gm = guess.grad_mask()
+    terms, grad, E, I = eng.loss_grad(X, batch, w, gm, want_spectra=True)
+    sums, gref, Eo, Io = co.loss_grad(cfg, sa, X, hb, w=w, gmask=gm)
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-8 and util.rel_err(I.cpu().numpy(), Io) < 1e-7
+    np.testing.assert_allclose(terms.cpu().numpy(), sums.sum(axis=0), rtol=1e-9)
+    g = grad.cpu().numpy()
+    act = np.nonzero(gm)[0]
+    for s in act:  # per column: relative to the column's largest entry, every lineout
+        assert np.max(np.abs(g[:, s] - gref[:, s])) < 1e-6 * np.max(np.abs(gref[:, s])), s
+    assert np.all(g[:, gm == 0] == 0.0)
