@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="lineouts per GPU")
     ap.add_argument("--ppp", type=int, default=1, help="points per pixel (1 -> 1024 wavelength points per feature)")
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="lineouts of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="lineouts of the CPU baseline (0 = skip)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: forward-only (not the headline metric)")
     ap.add_argument("--dlm", action="store_true",
                     help="variant: the reference's canonical active set {Te, ne, m, amp1, amp2, lam} with a per-lineout "
