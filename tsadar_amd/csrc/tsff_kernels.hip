@@ -31,6 +31,11 @@ struct KStatic {
   const double* taps[2];
   int ntaps[2];              // length of the bin-averaged IRF taps hb
   int toff[2];               // ybin[p] = sum_s hb[s] x[p * ppp + toff + s]
+  // phase-layout convolution (points_per_pixel = 1, 256 threads per feature; see "IRF convolution" in k_spectrum):
+  const double* ptaps[2];    // hb zero-padded by 3 + rounding on both sides: ptaps[3 + s] = hb[s]
+  int cf_i0[2], cf_na[2], cf_a0[2];  // forward: first padded-tap index, tap groups of 4, first slot offset (u0 / 4)
+  int ca_i0[2], ca_na[2], ca_a0[2];  // adjoint: first (descending) padded-tap index, groups, slot offset
+  int hs;                    // halo of a phase array in slots of 4 samples
   int halo;                  // zero padding on both sides of the LDS spectrum buffers (>= every |tap offset|)
   int halo_bins;             // the same for the per-bin adjoint buffer
   const uint8_t* mask[2];    // [1024]
@@ -592,13 +597,24 @@ struct Smem {
   double* red;    // [8 * kNP_MAX + 64]
 };
 
+// one spectrum / per-bin adjoint buffer: linear with a zero halo, or four phase arrays (sample j -> phase j & 3, slot
+// j >> 2) with a halo of hs slots each -- sized for the larger of the two layouts
+__host__ __device__ inline size_t xbuf_doubles(const KStatic& S) {
+  const size_t lin = (size_t)S.npts + 2 * (size_t)S.halo, ph = (size_t)S.npts + 8 * (size_t)S.hs;
+  return (lin > ph ? lin : ph) + 2;
+}
+__host__ __device__ inline size_t ybuf_doubles(const KStatic& S) {
+  const size_t lin = (size_t)TSFF_NBINS + 2 * (size_t)S.halo_bins, ph = (size_t)TSFF_NBINS + 8 * (size_t)S.hs;
+  return (lin > ph ? lin : ph) + 2;
+}
+
 // LDS budget (in doubles) of one k_spectrum / k_form_factor workgroup holding `nfeat` features;
 // with_m: tangent tables of the DLM order; with_ks: k_s cache
 __host__ __device__ inline size_t smem_doubles(const KStatic& S, int nfeat, bool with_m, bool with_ks) {
   size_t n = 2 * (size_t)(kNXi2 + S.nvx) + kNXi2 + 4 * (size_t)S.nvx;                    // zp, ht, W, hc
   if (with_m) n += 4 * (size_t)S.nvx + kNXi2;                                               // hcm, Wm
-  n += (size_t)nfeat * ((size_t)S.npts + 2 * (size_t)S.halo);                               // spectrum buffers
-  n += (size_t)nfeat * ((size_t)TSFF_NBINS + 2 * (size_t)S.halo_bins);                      // per-bin adjoint buffers
+  n += (size_t)nfeat * xbuf_doubles(S);                                                     // spectrum buffers
+  n += (size_t)nfeat * ybuf_doubles(S);                                                     // per-bin adjoint buffers
   if (with_ks) n += (size_t)nfeat * ((size_t)S.npts + 2);                                   // k_s cache
   n += S.ntaps[0] + S.ntaps[1] + 2 * (size_t)S.n_angles + 11 * kNP_MAX + 66;                // taps, angles, phys, scratch
   return n;
@@ -612,8 +628,8 @@ __device__ __forceinline__ Smem carve(unsigned char* smem, const KStatic& S, int
   double* p = m.W + kNXi2;
   // one buffer per feature holds the model spectrum x and later its adjoint, another the adjoint of the binned
   // spectrum; zero halos on both sides so the convolutions need no bounds checks
-  m.x = p; p += (size_t)nfeat * (S.npts + 2 * S.halo);
-  m.yb = p; p += (size_t)nfeat * (TSFF_NBINS + 2 * S.halo_bins);
+  m.x = p; p += (size_t)nfeat * xbuf_doubles(S);
+  m.yb = p; p += (size_t)nfeat * ybuf_doubles(S);
   m.hc = reinterpret_cast<double2*>(p); p += 4 * (size_t)S.nvx;
   m.hcm = nullptr; m.Wm = nullptr;
   if (with_m) { m.hcm = reinterpret_cast<double2*>(p); p += 4 * (size_t)S.nvx; m.Wm = p; p += kNXi2; }
@@ -752,7 +768,9 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   constexpr int NW = TPF / 64;          // wavefronts per feature
   constexpr int BPT = TSFF_NBINS / TPF;  // output bins per thread
   const int half = tid / TPF, ht = tid % TPF, lane = tid & 63, hw = ht >> 6;
-  const int f = interleaved ? f_il : f0 + half;  // feature of this group (wavefront-uniform)
+  // feature of this group: wavefront-uniform, kept in an SGPR so that everything indexed by it (tap counts, axis
+  // pointers, the padded taps of the convolution) is read through scalar loads
+  const int f = __builtin_amdgcn_readfirstlane(interleaved ? f_il : f0 + half);
   extern __shared__ __align__(16) unsigned char smem[];
   const Smem m = carve(smem, S, nfeat, GM != 0, use_ks);
   Tables T;
@@ -765,12 +783,20 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   const int npts = S.npts, ppp = S.ppp, G = S.G, NA = S.n_angles, nstrips = S.npts / kStrip;
   const double invG = 1.0 / (double)G;
   // (pointer arithmetic on the LDS base, not a runtime-indexed pointer array: keeps ds_* addressing)
-  const int H = S.halo;
-  double* __restrict__ xs = m.x + half * (S.npts + 2 * H) + H;
-  const int Hb = S.halo_bins;
-  double* __restrict__ ybs = m.yb + half * (TSFF_NBINS + 2 * Hb) + Hb;
-  for (int i = ht - H; i < npts + H; i += TPF) xs[i] = 0.0;
-  for (int i = ht - Hb; i < TSFF_NBINS + Hb; i += TPF) ybs[i] = 0.0;
+  // Layout of the spectrum buffer x (and of the per-bin adjoint buffer yb).  Linear: x[H + j] with a zero halo.  Phase
+  // layout (points_per_pixel = 1, 256 threads per feature): sample j lives at x[(j & 3) Ls + (j >> 2) + hs], four
+  // arrays of Ls = npts/4 + 2 hs slots.  A thread owns the four CONSECUTIVE samples 4 ht .. 4 ht + 3 (its strip of the
+  // sweeps, its bins of the convolution), and every access of a wavefront is to 64 consecutive doubles of one phase
+  // array (no bank conflicts), which lets the convolution slide a register window over adjacent samples (below).
+  const bool ph = (TPF == kHalf) && ppp == 1;
+  const int H = S.halo, Hb = S.halo_bins, hs = S.hs, Ls = npts / 4 + 2 * hs;
+  double* __restrict__ xs = m.x + half * xbuf_doubles(S);
+  double* __restrict__ ybs = m.yb + half * ybuf_doubles(S);
+  auto XA = [&](int j) { return ph ? (j & 3) * Ls + (j >> 2) + hs : H + j; };     // sample j of x
+  auto YA = [&](int pbin) { return ph ? (pbin & 3) * Ls + (pbin >> 2) + hs : Hb + pbin; };  // bin p of yb
+  auto PB = [&](int r) { return ph ? 4 * ht + r : ht + TPF * r; };                // r-th bin of this thread
+  for (int i = ht; i < (int)xbuf_doubles(S); i += TPF) xs[i] = 0.0;
+  for (int i = ht; i < (int)ybuf_doubles(S); i += TPF) ybs[i] = 0.0;
   __syncthreads();
 
   // ================= forward sweep over (gradient point, lambda strip, angle) =================
@@ -807,7 +833,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
           wnext = omgs[min(j + 2, npts - 1)];
           Base b1;
           base_eval<NI>(wsn, use_ks ? ksc[min(j + 1, npts - 1)] : ks_eval(wsn, L.wpe2), ct, L, T, b1);
-          xs[j] += wa * point_forward<NI>(ws, b0, b1, has_next, L, T);
+          xs[XA(j)] += wa * point_forward<NI>(ws, b0, b1, has_next, L, T);
           b0 = b1;
           ws = wsn;
         }
@@ -818,7 +844,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     for (int st = ht; st < nstrips; st += TPF) {
       const int j0 = kStrip * st;
 #pragma unroll
-      for (int q = 0; q < kStrip; ++q) xs[j0 + q] *= S.filt[j0 + q];
+      for (int q = 0; q < kStrip; ++q) xs[XA(j0 + q)] *= S.filt[j0 + q];
     }
   __syncthreads();
 
@@ -830,8 +856,31 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   double ybin[BPT];
 #pragma unroll
   for (int r = 0; r < BPT; ++r) ybin[r] = 0.0;
-  {
-    const double* __restrict__ x0 = xs + toff + ht * ppp;
+  if (ph) {
+    // y[4 ht + r] = sum_u g(u) x[4 ht + r + u]: the taps are walked in groups of four (u = 4 a + c); a group needs the
+    // seven samples V[k] = x[4 (ht + a) + k], of which three carry over from the previous group -- four LDS reads
+    // (conflict-free, one per phase array) and four scalar tap loads per sixteen FMAs, against five LDS reads per four
+    // FMAs of the linear form: the convolution stops being LDS-bandwidth bound.
+    // (constant address space: the padded taps are read-only for the whole launch, so the wavefront-uniform reads
+    //  below become scalar loads and cost neither LDS bandwidth nor vector-memory instructions)
+    typedef const double __attribute__((address_space(4))) cdouble;
+    cdouble* pt = (cdouble*)(S.ptaps[f] + S.cf_i0[f]);
+    const double* __restrict__ X0 = xs, * __restrict__ X1 = xs + Ls, * __restrict__ X2 = xs + 2 * Ls, * __restrict__ X3 = xs + 3 * Ls;
+    int sl = ht + S.cf_a0[f] + hs;
+    double V0 = X0[sl], V1 = X1[sl], V2 = X2[sl];
+    const int na = S.cf_na[f];
+    for (int a = 0; a < na; ++a, ++sl) {
+      const double V3 = X3[sl], V4 = X0[sl + 1], V5 = X1[sl + 1], V6 = X2[sl + 1];
+      const double g0 = pt[4 * a], g1 = pt[4 * a + 1], g2 = pt[4 * a + 2], g3 = pt[4 * a + 3];
+      // (index % BPT: the branch is dead, but must compile, in the 512-threads-per-feature instantiation)
+      ybin[0] += g0 * V0 + g1 * V1 + g2 * V2 + g3 * V3;
+      ybin[1 % BPT] += g0 * V1 + g1 * V2 + g2 * V3 + g3 * V4;
+      ybin[2 % BPT] += g0 * V2 + g1 * V3 + g2 * V4 + g3 * V5;
+      ybin[3 % BPT] += g0 * V3 + g1 * V4 + g2 * V5 + g3 * V6;
+      V0 = V4; V1 = V5; V2 = V6;
+    }
+  } else {
+    const double* __restrict__ x0 = xs + H + toff + ht * ppp;
     const int rs = TPF * ppp;
 #pragma unroll 4
     for (int t = 0; t < nh; ++t) {  // one tap read feeds all the thread's bins
@@ -841,10 +890,10 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     }
   }
   double M = ybin[0];
-  int pstar = ht;
+  int pstar = PB(0);
 #pragma unroll
   for (int r = 1; r < BPT; ++r)
-    if (ybin[r] > M) { M = ybin[r]; pstar = ht + TPF * r; }
+    if (ybin[r] > M) { M = ybin[r]; pstar = PB(r); }
   half_argmax<NW>(M, pstar, m.red, half, hw, lane);
   const double invM = 1.0 / M;
   const double amps = K.amps[f][b];
@@ -859,7 +908,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   double s0 = 0.0, s1 = 0.0;
 #pragma unroll
   for (int r = 0; r < BPT; ++r) {
-    const int pb = ht + TPF * r;
+    const int pb = PB(r);
     double A;
     if (f == TSFF_FEATURE_ELE) A = amps * (lamb[pb] < p_lam ? p_amp1 : p_amp2);  // irf.py:126-130
     else A = amps * p_amp3;                                                      // irf.py:76
@@ -906,7 +955,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   double sn = 0.0, a1b = 0.0, a2b = 0.0;
 #pragma unroll
   for (int r = 0; r < BPT; ++r) {
-    const int pb = ht + TPF * r;
+    const int pb = PB(r);
     const double u = Tb[r] * ybin[r] * invM;  // dL/dA_p
     sn += u * Ap[r];
     if (f == TSFF_FEATURE_ELE) { if (lamb[pb] < p_lam) a1b += u * amps; else a2b += u * amps; }
@@ -917,18 +966,43 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
   a2b = half_sum<NW>(a2b, m.red, half, hw, lane);
 #pragma unroll
   for (int r = 0; r < BPT; ++r) {
-    const int pb = ht + TPF * r;
+    const int pb = PB(r);
     double yb = Tb[r] * Ap[r] * invM;
     if (pb == pstar) yb -= sn * invM;
-    ybs[pb] = yb;
+    ybs[YA(pb)] = yb;
   }
   __syncthreads();
   // ================= adjoint of convolution + binning: xbar_i = filt_i sum_p ybar_p hb[i - p ppp - toff] =================
-  if (ppp == 1) {
+  if (ph) {
+    // xbar[4 ht + r] = sum_u g'(u) ybar[4 ht + r + u], g'(u) = hb[-toff - u]: the same sliding window, taps read backwards
+    typedef const double __attribute__((address_space(4))) cdouble;
+    cdouble* pt = (cdouble*)(S.ptaps[f] + S.ca_i0[f]);
+    const double* __restrict__ Y0 = ybs, * __restrict__ Y1 = ybs + Ls, * __restrict__ Y2 = ybs + 2 * Ls, * __restrict__ Y3 = ybs + 3 * Ls;
+    int sl = ht + S.ca_a0[f] + hs;
+    double V0 = Y0[sl], V1 = Y1[sl], V2 = Y2[sl];
+    double sx[4] = {0.0, 0.0, 0.0, 0.0};
+    const int na = S.ca_na[f];
+    for (int a = 0; a < na; ++a, ++sl) {
+      const double V3 = Y3[sl], V4 = Y0[sl + 1], V5 = Y1[sl + 1], V6 = Y2[sl + 1];
+      const double g0 = pt[-4 * a], g1 = pt[-4 * a - 1], g2 = pt[-4 * a - 2], g3 = pt[-4 * a - 3];
+      sx[0] += g0 * V0 + g1 * V1 + g2 * V2 + g3 * V3;
+      sx[1] += g0 * V1 + g1 * V2 + g2 * V3 + g3 * V4;
+      sx[2] += g0 * V2 + g1 * V3 + g2 * V4 + g3 * V5;
+      sx[3] += g0 * V3 + g1 * V4 + g2 * V5 + g3 * V6;
+      V0 = V4; V1 = V5; V2 = V6;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * ht + r;
+      double v = sx[r];
+      if (f == TSFF_FEATURE_ELE && S.filt) v *= S.filt[i];
+      xs[XA(i)] = v * invG;
+    }
+  } else if (ppp == 1) {
     double sx[BPT];
 #pragma unroll
     for (int r = 0; r < BPT; ++r) sx[r] = 0.0;
-    const double* __restrict__ y0 = ybs - toff + ht;
+    const double* __restrict__ y0 = ybs + Hb - toff + ht;
 #pragma unroll 4
     for (int t = 0; t < nh; ++t) {
       const double g = taps[t];
@@ -940,16 +1014,16 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       const int i = ht + TPF * r;
       double v = sx[r];
       if (f == TSFF_FEATURE_ELE && S.filt) v *= S.filt[i];
-      xs[i] = v * invG;
+      xs[H + i] = v * invG;
     }
   } else {
     for (int i = ht; i < npts; i += TPF) {
       const int q = i - toff;           // >= 0: toff = -dmax <= 0
       int pb = q / ppp;
       double sv = 0.0;
-      for (int t = q - pb * ppp; t < nh; t += ppp, --pb) sv += taps[t] * ybs[pb];
+      for (int t = q - pb * ppp; t < nh; t += ppp, --pb) sv += taps[t] * ybs[Hb + pb];
       if (f == TSFF_FEATURE_ELE && S.filt) sv *= S.filt[i];
-      xs[i] = sv * invG;
+      xs[H + i] = sv * invG;
     }
   }
   __syncthreads();
@@ -1000,7 +1074,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
           base_eval<NI>(wsn, use_ks ? ksc[min(j + 1, npts - 1)] : ks_eval(wsn, L.wpe2), ct, L, T, b1);
           BaseAdj ba;
           double xen, Fn;
-          point_reverse<NI, GM>(ws, b0, b1, has_next, L, T, xs[j] * wa, ba, xen, Fn, LB, fa);
+          point_reverse<NI, GM>(ws, b0, b1, has_next, L, T, xs[XA(j)] * wa, ba, xen, Fn, LB, fa);
           ba.xe += cxe; ba.F += cF;
           base_reverse<NI, GM>(ct, b0, L, T, ba, LB, fa);
           cxe = xen; cF = Fn;
