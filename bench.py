@@ -190,9 +190,9 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            Xd = eng.dev(Xh)
+            Xd = eng.upload(Xh)
             eng.loss_grad(Xd, batch, w, gmask, out=(terms, grad))
-            host = torch.cat([terms, grad[:, act].t().reshape(-1)]).cpu()
+            host = eng.download(torch.cat([terms, grad[:, act].t().reshape(-1)]))
         torch.cuda.synchronize()
         pcie_value = B * args.steps / (time.perf_counter() - t1)
 

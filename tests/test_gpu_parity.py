@@ -1037,3 +1037,22 @@ def test_forward_pass_like_calc_series(torch_mod):
     Eo, _, lamE, _ = orc.ts_diag(cfg, sa, normed, unit, activate=False)
     assert util.rel_err(res["ThryE"][0], Eo) < 1e-8
     np.testing.assert_allclose(res["lamAxisE"][0], lamE, rtol=1e-12)
+
+
+def test_nan_outside_fit_ranges_is_ignored(torch_mod):
+    """Measured data outside every fit range never enter the loss (loss_function.py:224-259 masks them to NaN and
+    nanmean drops them); NaNs stored there must not leak into the loss or the gradient."""
+    cfg = decks.deck_fit()
+    B = 3
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B, seed=5)
+    eng = _engine(cfg, sa)
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    X = util.normed_to_matrix(normed, 1)
+    gm = eng.slots.active.astype(np.uint8)
+    t0, g0, _, _ = eng.loss_grad(X, batch, w, gm)
+    bad = {k: (np.array(v, dtype=np.float64, copy=True) if k in ("e_data", "i_data") else v) for k, v in batch.items()}
+    bad["e_data"][:, eng.mask_ele == 0] = np.nan
+    bad["i_data"][:, eng.mask_ion == 0] = np.nan
+    t1, g1, _, _ = eng.loss_grad(X, bad, w, gm)
+    np.testing.assert_array_equal(t0.cpu().numpy(), t1.cpu().numpy())
+    np.testing.assert_array_equal(g0.cpu().numpy(), g1.cpu().numpy())

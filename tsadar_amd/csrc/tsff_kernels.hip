@@ -937,7 +937,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
         double w = 0.0;
         if (mk & 1) { s0 += e; w += (f == TSFF_FEATURE_ELE ? K.wts[1] : K.wts[0]); }
         if (mk & 2) { s1 += e; w += K.wts[2]; }
-        Tb[r] = det * w;
+        Tb[r] = w != 0.0 ? det * w : 0.0;  // (samples outside every fit range may hold anything, NaN included)
       }
     }
   }

@@ -225,6 +225,7 @@ class Engine:
         self.fit_blue, self.fit_red, self.fit_iaw = bool(ext.get("fit_EPWb")), bool(ext.get("fit_EPWr")), bool(ext.get("fit_IAW"))
 
         self._keep = keep
+        self._staging = {}
         self._cfg_struct = c
         h = C.c_void_p()
         rc = self.lib.tsff_create(C.byref(c), C.byref(h))
@@ -258,6 +259,33 @@ class Engine:
     @staticmethod
     def _ptr(t):
         return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+    # ---- host <-> device staging of the per-step vectors (pinned buffers: a fit step moves ~0.5 MB in and ~0.2 MB out) ----
+    def upload(self, a: np.ndarray):
+        """NumPy array -> device tensor through a persistent pinned staging buffer (asynchronous copy on the current stream)."""
+        torch = self.torch
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        key = ("in", a.shape)
+        buf = self._staging.get(key)
+        if buf is None:
+            buf = (torch.empty(a.shape, dtype=torch.float64).pin_memory(), torch.empty(a.shape, dtype=torch.float64, device=self.device))
+            self._staging[key] = buf
+        pin, dev = buf
+        pin.numpy()[...] = a
+        dev.copy_(pin, non_blocking=True)
+        return dev
+
+    def download(self, t) -> np.ndarray:
+        """Device tensor -> NumPy (pinned staging, one synchronisation of the current stream)."""
+        torch = self.torch
+        key = ("out", tuple(t.shape))
+        pin = self._staging.get(key)
+        if pin is None:
+            pin = torch.empty(tuple(t.shape), dtype=t.dtype).pin_memory()
+            self._staging[key] = pin
+        pin.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return pin.numpy().copy()
 
     def _sync_stream(self):
         s = self.torch.cuda.current_stream(self.device)

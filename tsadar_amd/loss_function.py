@@ -75,6 +75,7 @@ class LossFunction:
         world, rank = self._world()
         w = eng.loss_weights(B * world, self.i_norm, self.e_norm, self.cfg["data"]["ion_loss_scale"])
         db = self._device_batch(eng, batch, B)
+        X = eng.upload(X)  # pinned staging, asynchronous H2D
         if ts_params.fval is not None:  # free-form f_e: explicit tables in, d loss / d fe out
             from . import distribution as Dist
 
@@ -165,7 +166,8 @@ class LossFunction:
         if getattr(self, "_gfe", None) is not None and ts_params.slots.fval_active:
             gact = torch.cat([gact, self._gfe.t().contiguous()])  # nvx more rows: d loss / d fe, chained on the host
         terms, gflat = D.allreduce_loss_grad(terms, gact, world, rank, self.pg)  # the one collective per step
-        host = torch.cat([terms, gflat]).cpu().numpy()  # single D2H copy: 3 + P*B doubles
+        out = torch.cat([terms, gflat])  # single D2H copy: 3 + P*B doubles (pinned staging on the engine)
+        host = eng.download(out) if hasattr(eng, "download") else out.cpu().numpy()
         value = float(np.dot(host[:3], w))
         flat = host[3:]
         if getattr(self, "_gfe", None) is not None and ts_params.slots.fval_active:
