@@ -989,7 +989,7 @@ def test_angular_vg_loss_finite_difference(torch_mod):
     np.testing.assert_allclose(res.x, [truth["Te"][0], truth["ne"][0]], atol=4e-2)
 
 
-@pytest.mark.parametrize("B", [256, 4096])
+@pytest.mark.parametrize("B", [37, 256, 4096])
 def test_full_batch_against_cpp_oracle(torch_mod, B):
     """BASELINE config 2's and config 3's batches (256 / 4096 lineouts) checked one by one -- spectra, loss sums and all six gradient columns --
     against the C++/OpenMP oracle (forward-mode dual numbers, pinned to the reference golden vector in
