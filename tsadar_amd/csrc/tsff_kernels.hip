@@ -1259,75 +1259,67 @@ __global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, in
 //   3. gradient of the projection, the two linear interpolations at |xi_e| and the rationally-centred integral
 //      over the nv-2 intervals (:372-387), spectrum assembly (:560-585).
 // ------------------------------------------------------------------------------------------
-// separable Hermite weights of the four nodes c-1..c+2 for cell c (0 <= c <= n-2) at local coordinate t
-__device__ __forceinline__ void hermite_weights(int c, int n, double t, double w[4]) {
+// interior-cell (Catmull-Rom) weights of the four nodes c-1..c+2
+__device__ __forceinline__ void catmull_rom(double t, double w[4]) {
   const double t2 = t * t, t3 = t2 * t;
-  const double h00 = 2.0 * t3 - 3.0 * t2 + 1.0, h01 = -2.0 * t3 + 3.0 * t2, h10 = t3 - 2.0 * t2 + t, h11 = t3 - t2;
-  // slope at node c: (f[c+1]-f[c-1])/2 inside, f[c+1]-f[c] at the left edge (units of the grid step)
-  w[0] = 0.0; w[1] = h00; w[2] = h01; w[3] = 0.0;
-  if (c == 0) { w[1] -= h10; w[2] += h10; }
-  else { w[0] -= 0.5 * h10; w[2] += 0.5 * h10; }
-  // slope at node c+1: (f[c+2]-f[c])/2 inside, f[c+1]-f[c] at the right edge
-  if (c == n - 2) { w[1] -= h11; w[2] += h11; }
-  else { w[1] -= 0.5 * h11; w[3] += 0.5 * h11; }
+  const double h10 = t3 - 2.0 * t2 + t, h11 = t3 - t2;
+  w[0] = -0.5 * h10;
+  w[1] = (2.0 * t3 - 3.0 * t2 + 1.0) - 0.5 * h11;
+  w[2] = (-2.0 * t3 + 3.0 * t2) + 0.5 * h10;
+  w[3] = 0.5 * h11;
 }
 
-// one bicubic sample of the table at (xq, yq).  When every lane of the wavefront is in an interior cell (the vast
-// majority of samples) the Catmull-Rom weights and 4 x 4 consecutive loads need no index clamps; otherwise the whole
-// wavefront takes the general path (edge cells, extrapolated samples) through hermite_weights.
-__device__ __forceinline__ double bicubic_sample(const double* __restrict__ F, int nv, int pitch, double v0, double dv,
+// One bicubic sample at (xq, yq) of a table that carries one GHOST row / column on every side, filled by linear
+// extrapolation (f[-1] = 2 f[0] - f[1], f[n] = 2 f[n-1] - f[n-2]; corners by both).  With those ghosts the Catmull-Rom
+// weights of an interior cell reproduce interpax's edge cells exactly -- its one-sided node slope f[1] - f[0] IS the
+// central slope (f[1] - f[-1]) / 2 of the extended sequence -- and its extrapolation (edge-cell polynomial continued
+// outside the grid, extrap=True) is the same formula with the cell index clamped and t left free.  Every sample then
+// takes one straight-line path: 4 x 4 consecutive entries, no index clamps, no divergence between lanes.
+// Fp points at the ghost corner; pitch = row pitch in doubles of the padded table.
+__device__ __forceinline__ double bicubic_sample(const double* __restrict__ Fp, int nv, int pitch, double v0, double dv,
                                                  double idv, double xq, double yq) {
-  const double ux = (xq - v0) * idv, uy = (yq - v0) * idv;
-  const double fx = floor(ux), fy = floor(uy);
-  int cx = (int)fx, cy = (int)fy;
-  if (__all(cx >= 1 && cx <= nv - 3 && cy >= 1 && cy <= nv - 3)) {  // wavefront-uniform: no divergence
-    const double tx = (xq - (v0 + cx * dv)) * idv, ty = (yq - (v0 + cy * dv)) * idv;
-    double wx[4], wy[4];
-    {
-      const double t2 = tx * tx, t3 = t2 * tx;
-      const double h10 = t3 - 2.0 * t2 + tx, h11 = t3 - t2;
-      wx[0] = -0.5 * h10;
-      wx[1] = (2.0 * t3 - 3.0 * t2 + 1.0) - 0.5 * h11;
-      wx[2] = (-2.0 * t3 + 3.0 * t2) + 0.5 * h10;
-      wx[3] = 0.5 * h11;
-    }
-    {
-      const double t2 = ty * ty, t3 = t2 * ty;
-      const double h10 = t3 - 2.0 * t2 + ty, h11 = t3 - t2;
-      wy[0] = -0.5 * h10;
-      wy[1] = (2.0 * t3 - 3.0 * t2 + 1.0) - 0.5 * h11;
-      wy[2] = (-2.0 * t3 + 3.0 * t2) + 0.5 * h10;
-      wy[3] = 0.5 * h11;
-    }
-    const double* __restrict__ r0 = F + (size_t)(cx - 1) * pitch + (cy - 1);
-    double v = 0.0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const double* __restrict__ row = r0 + (size_t)m * pitch;
-      double r = wy[0] * row[0];
-      r += wy[1] * row[1];
-      r += wy[2] * row[2];
-      r += wy[3] * row[3];
-      v += wx[m] * r;
-    }
-    return v;
-  }
+  int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
   cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
   cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
   double wx[4], wy[4];
-  hermite_weights(cx, nv, (xq - (v0 + cx * dv)) * idv, wx);
-  hermite_weights(cy, nv, (yq - (v0 + cy * dv)) * idv, wy);
+  catmull_rom((xq - (v0 + cx * dv)) * idv, wx);
+  catmull_rom((yq - (v0 + cy * dv)) * idv, wy);
+  const double* __restrict__ q0 = Fp + (size_t)cx * pitch + cy;  // padded index of node (cx - 1, cy - 1)
   double v = 0.0;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    const int rx = min(max(cx - 1 + m, 0), nv - 1);   // (clamped rows carry zero weight)
-    const double* __restrict__ row = F + (size_t)rx * pitch;
-    double r = 0.0;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) r += wy[n] * row[min(max(cy - 1 + n, 0), nv - 1)];
-    v += wx[m] * r;
+    const double* __restrict__ row = q0 + (size_t)m * pitch;
+    v += wx[m] * (wy[0] * row[0] + wy[1] * row[1] + wy[2] * row[2] + wy[3] * row[3]);
   }
   return v;
+}
+
+// ghost cells of a padded table P[(nv + 2)][pitch] whose interior [1..nv][1..nv] is filled: rows first, then columns
+// (which also makes the corners).  Called by all threads of a workgroup (LDS) or of a grid (global copy).
+__device__ __forceinline__ void ghost_rows(double* __restrict__ P, int nv, int pitch, int tid, int nthr) {
+  for (int c = tid; c < nv; c += nthr) {
+    P[c + 1] = 2.0 * P[pitch + c + 1] - P[2 * pitch + c + 1];
+    P[(size_t)(nv + 1) * pitch + c + 1] = 2.0 * P[(size_t)nv * pitch + c + 1] - P[(size_t)(nv - 1) * pitch + c + 1];
+  }
+}
+__device__ __forceinline__ void ghost_cols(double* __restrict__ P, int nv, int pitch, int tid, int nthr) {
+  for (int r = tid; r < nv + 2; r += nthr) {
+    double* row = P + (size_t)r * pitch;
+    row[0] = 2.0 * row[1] - row[2];
+    row[nv + 1] = 2.0 * row[nv] - row[nv - 1];
+  }
+}
+
+// padded copy in global memory for tables that do not fit LDS: one workgroup per table
+__global__ __launch_bounds__(kThreads) void k_pad2d(const double* __restrict__ F, int nv, double* __restrict__ P) {
+  const int pitch = nv + 2;
+  const double* __restrict__ Fb = F + (size_t)blockIdx.x * nv * nv;
+  double* __restrict__ Pb = P + (size_t)blockIdx.x * (nv + 2) * pitch;
+  for (int i = threadIdx.x; i < nv * nv; i += kThreads) Pb[(size_t)(i / nv + 1) * pitch + (i % nv + 1)] = Fb[i];
+  __syncthreads();
+  ghost_rows(Pb, nv, pitch, threadIdx.x, kThreads);
+  __syncthreads();
+  ghost_cols(Pb, nv, pitch, threadIdx.x, kThreads);
 }
 
 // LDS: true -> the nv x nv table is staged once per (persistent) workgroup in LDS (nv <= 128: 128 KB); false -> the
@@ -1344,11 +1336,17 @@ __device__ __forceinline__ double bicubic_sample(const double* __restrict__ F, i
 #define TSFF_2D_GROUPS_L2 1
 #endif
 constexpr int kSc2 = 40;  // doubles of per-group scalar scratch
-// LDS rows are padded by one double: with a power-of-two pitch every row starts in the same bank and the lanes of a
-// wavefront (neighbouring points of a rotated line) collide whenever the line runs along the first table axis
-__host__ __device__ inline int pitch2d(int nv, bool lds) { return lds ? nv + 1 : nv; }
+// Row pitch of the padded (nv + 2)^2 table.  In LDS it is made odd: with an even (worse: power-of-two) pitch the rows
+// start in the same banks and the lanes of a wavefront (neighbouring points of a rotated line) collide whenever the line
+// runs along the first table axis.
+__host__ __device__ inline int pitch2d(int nv, bool lds) { return lds ? ((nv + 2) | 1) : nv + 2; }
+// per-group scratch: f1, d1 [nv], part [nparts][nv] (nparts = 4, 2, 1 for nv <= 64, 128, larger), red [8], scalars
+__host__ __device__ inline size_t group2d_doubles(int nv) {
+  const int nparts = nv <= 64 ? 4 : (nv <= 128 ? 2 : 1);
+  return (2 + (size_t)nparts) * nv + 8 + kSc2;
+}
 __host__ __device__ inline size_t smem2d_doubles(int nv, bool lds, int ng) {
-  return (size_t)ng * (6 * (size_t)nv + 8 + kSc2) + (lds ? (size_t)nv * pitch2d(nv, true) : 0);
+  return (size_t)ng * group2d_doubles(nv) + (lds ? (size_t)(nv + 2) * pitch2d(nv, true) : 0);
 }
 template <int NI, bool LDS, int kG2>
 __global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d(KStatic S, const double* __restrict__ phys,
@@ -1357,23 +1355,27 @@ __global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d(KStatic S, co
                                                                    long pend, double* __restrict__ P) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int grp = threadIdx.x >> 8, gt = threadIdx.x & (kThreads - 1);
-  double* gbase = reinterpret_cast<double*>(smem) + (size_t)grp * (6 * (size_t)nv + 8 + kSc2);
-  double* f1 = gbase;              // [nv] projected distribution
-  double* d1 = f1 + nv;            // [nv] its gradient
-  double* part = d1 + nv;          // [4][nv] partial column sums
-  double* red = part + 4 * nv;     // [8]
-  double* sc = red + 8;            // [kSc2] point scalars
-  double* Fl = reinterpret_cast<double*>(smem) + (size_t)kG2 * (6 * (size_t)nv + 8 + kSc2);  // [nv][nv] (LDS variant)
-  const int NA = S.n_angles, G = S.G, npts = S.npts;
   // thread -> (column iy, part of the ix range): nparts = 256 / nvp with nvp = nv rounded up to 64, 128 or 256
   const int nvp = nv <= 64 ? 64 : (nv <= 128 ? 128 : 256);
   const int nparts = nv <= 256 ? kThreads / nvp : 1;
+  double* gbase = reinterpret_cast<double*>(smem) + (size_t)grp * group2d_doubles(nv);
+  double* f1 = gbase;              // [nv] projected distribution
+  double* d1 = f1 + nv;            // [nv] its gradient
+  double* part = d1 + nv;          // [nparts][nv] partial column sums
+  double* red = part + (nv <= 64 ? 4 : (nv <= 128 ? 2 : 1)) * nv;  // [8]
+  double* sc = red + 8;            // [kSc2] point scalars
+  double* Fl = reinterpret_cast<double*>(smem) + (size_t)kG2 * group2d_doubles(nv);  // padded table (LDS variant)
+  const int NA = S.n_angles, G = S.G, npts = S.npts;
   const double dv = 12.0 / nv, v0 = -6.0 + 0.5 * dv, idv = 1.0 / dv;  // base.py:333-335
   const int pitch = pitch2d(nv, LDS);
-  if (LDS) {
-    for (int i = threadIdx.x; i < nv * nv; i += kG2 * kThreads) Fl[(i / nv) * pitch + (i % nv)] = Fg[i];
+  if (LDS) {  // Fg: the plain nv x nv table; the ghost cells are made here
+    for (int i = threadIdx.x; i < nv * nv; i += kG2 * kThreads) Fl[(i / nv + 1) * pitch + (i % nv + 1)] = Fg[i];
+    __syncthreads();
+    ghost_rows(Fl, nv, pitch, threadIdx.x, kG2 * kThreads);
+    __syncthreads();
+    ghost_cols(Fl, nv, pitch, threadIdx.x, kG2 * kThreads);
   }
-  const double* __restrict__ F = LDS ? Fl : Fg;
+  const double* __restrict__ F = LDS ? Fl : Fg;  // (not LDS: Fg is the padded copy made by k_pad2d)
   const long stride = (long)gridDim.x * kG2;
   for (long base = pbegin + (long)blockIdx.x * kG2; base < pend; base += stride) {
     const long pid = base + grp;
