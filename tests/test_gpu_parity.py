@@ -1056,3 +1056,42 @@ def test_nan_outside_fit_ranges_is_ignored(torch_mod):
     t1, g1, _, _ = eng.loss_grad(X, bad, w, gm)
     np.testing.assert_array_equal(t0.cpu().numpy(), t1.cpu().numpy())
     np.testing.assert_array_equal(g0.cpu().numpy(), g1.cpu().numpy())
+
+
+def test_launch_plans_agree(torch_mod):
+    """The three launch plans of k_spectrum give the same numbers: interleaved (one 256-thread workgroup per lineout and
+    feature, default), fused (both features in one 512-thread workgroup), and -- with 5 points per pixel, where two
+    features do not fit the LDS of a CU -- one launch per feature accumulating into the gradient (checked against the
+    C++ oracle)."""
+    from oracle import c_oracle as co
+
+    cfg = decks.deck_fit()
+    B = 5
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B, seed=77)
+    eng = _engine(cfg, sa)
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    X = util.normed_to_matrix(normed, 1)
+    gm = eng.slots.active.astype(np.uint8)
+    out = {}
+    for plan in (0, 1):
+        eng.set_launch_plan(plan)
+        t, g, E, I = eng.loss_grad(X, batch, w, gm, want_spectra=True)
+        out[plan] = [a.cpu().numpy() for a in (t, g, E, I)]
+    eng.set_launch_plan(0)
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    np.testing.assert_array_equal(out[0][3], out[1][3])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-13, atol=1e-18)
+    # 5 points per pixel, both features: split launches
+    cfg5 = decks.deck_fit(points_per_pixel=5)
+    sa5, batch5, normed5, i5, e5 = _loss_setup(cfg5, 2, seed=78)
+    eng5 = _engine(cfg5, sa5)
+    w5 = eng5.loss_weights(2, i5, e5, cfg5["data"]["ion_loss_scale"])
+    X5 = util.normed_to_matrix(normed5, 1)
+    t5, g5, E5, I5 = eng5.loss_grad(X5, batch5, w5, gm, want_spectra=True)
+    sums, gref, Eo, Io = co.loss_grad(cfg5, sa5, X5, batch5, w=w5, gmask=gm)
+    assert util.rel_err(E5.cpu().numpy(), Eo) < 1e-8 and util.rel_err(I5.cpu().numpy(), Io) < 1e-7
+    np.testing.assert_allclose(t5.cpu().numpy(), sums.sum(axis=0), rtol=1e-9)
+    g5 = g5.cpu().numpy()
+    for s in np.nonzero(gm)[0]:
+        assert np.max(np.abs(g5[:, s] - gref[:, s])) < 1e-6 * np.max(np.abs(gref[:, s])), s
