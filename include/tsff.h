@@ -201,6 +201,11 @@ typedef struct tsff_ats_config {
 } tsff_ats_config;
 int tsff_ats_setup(tsff_handle *h, const tsff_ats_config *cfg);
 int tsff_ats_spectrum(tsff_handle *h, const double *P, const double *e_amps /* device [rows] */, double lam, double amp1, double amp2, double *ThryE);
+/* Reverse of tsff_ats_spectrum: given Ebar = d loss / d ThryE (device, [rows][npts / lam_step]) -> Pbar = d loss / d P
+ * (device, [G][npts][n_angles]) and amp_bar[2] = d loss / d (amp1, amp2) (host).  `lam` enters the model only through
+ * the blue / red split of the wavelength axis and carries no gradient, like in the reference's jnp.where. */
+int tsff_ats_adjoint(tsff_handle *h, const double *P, const double *e_amps, double lam, double amp1, double amp2,
+                     const double *Ebar, double *Pbar, double *amp_bar);
 
 /* ThomsonScatteringDiagnostic.__call__: ThryE/ThryI [B][1024].  noise_* may be NULL (= 0).
  * params: normalised leaves [B][NP]; fe: [B][nvx] when fe_mode == PER_LINEOUT else NULL. */

@@ -1095,3 +1095,41 @@ def test_launch_plans_agree(torch_mod):
     g5 = g5.cpu().numpy()
     for s in np.nonzero(gm)[0]:
         assert np.max(np.abs(g5[:, s] - gref[:, s])) < 1e-6 * np.max(np.abs(gref[:, s])), s
+
+
+@pytest.mark.parametrize("ccd,n_lam,start,end", [((1024, 1024), 1024, 90, 950), ((128, 256), 256, 10, 110)])
+def test_ats_adjoint_directional_derivatives(torch_mod, ccd, n_lam, start, end):
+    """Reverse of the ARTS instrument chain (tsff_ats_adjoint): for a random linear functional <Ebar, ThryE(P)> the
+    adjoint image Pbar and the amplitude adjoints against central differences of the forward chain along random
+    directions (the chain has kinks only at ties of the row maxima)."""
+    cfg = decks.deck_angular(1, 64, ccd, start, end)
+    sa = _angular_sa(cfg)
+    eng = _engine(cfg, sa, fe_mode=L.FE_PER_LINEOUT)
+    normed = util.random_lineouts(cfg, 1, seed=5)
+    phys = orc.physical_params(cfg["parameters"], normed, True)
+    X = util.normed_to_matrix(phys, 1)
+    P = eng.form_factor(0, X, orc.dlm_fe(2.7, 64)[None, :])[0]
+    wid = cfg["other"]["PhysParams"]["widIRF"]
+    eng.ats_setup(sa["weights"], sa["angAxis"], wid["spect_FWHM_ele"] / 2.3548, wid["ang_FWHM_ele"] / 2.3548,
+                  1024 // n_lam, 1024 // ccd[0], start, end)
+    rows = end - start
+    rng = np.random.default_rng(11)
+    e_amps = rng.uniform(0.5, 2.0, rows)
+    Ebar = rng.normal(size=(rows, n_lam))
+    lam, a1, a2 = 526.5, 0.8, 1.3
+    Pbar, (a1b, a2b) = eng.ats_adjoint(P, e_amps, lam, a1, a2, Ebar)
+    Pbar = Pbar.cpu().numpy()
+    Pn = P.cpu().numpy()
+
+    def func(Pm, b1=a1, b2=a2):
+        return float(np.sum(Ebar * eng.ats_spectrum(Pm, e_amps, lam, b1, b2).cpu().numpy()))
+
+    for k in range(3):
+        d = Pn * rng.normal(size=Pn.shape)
+        h = 1e-6
+        fd = (func(Pn + h * d) - func(Pn - h * d)) / (2 * h)
+        an = float(np.sum(Pbar * d))
+        assert abs(fd - an) < 2e-5 * max(abs(an), abs(fd), 1e-30), (k, fd, an)
+    h = 1e-6
+    assert abs((func(Pn, a1 + h) - func(Pn, a1 - h)) / (2 * h) - a1b) < 1e-7 * abs(a1b)
+    assert abs((func(Pn, a1, a2 + h) - func(Pn, a1, a2 - h)) / (2 * h) - a2b) < 1e-7 * abs(a2b)

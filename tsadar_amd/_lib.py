@@ -113,6 +113,7 @@ _SIGNATURES = {
                                             C.c_int64, C.c_int64, _vp]),
     "tsff_ats_setup": (C.c_int, [_vp, C.POINTER(TsffAtsConfig)]),
     "tsff_ats_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
+    "tsff_ats_adjoint": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, c_double_p]),
     "tsff_forward": (C.c_int, [_vp] + [_vp] * 6 + [C.c_int32, _vp, _vp]),
     "tsff_loss_grad": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, _vp, _vp, _vp, _vp]),
     "tsff_loss_grad_fe": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, _vp, _vp, _vp, _vp, _vp]),

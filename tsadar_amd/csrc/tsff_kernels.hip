@@ -1590,6 +1590,132 @@ __global__ __launch_bounds__(kThreads) void k_ats_resunit(const double* __restri
   }
 }
 
+// ---- adjoint of the ARTS instrument chain (reverse of the five kernels above) ----
+// per angular pixel r: maxima of the unconvolved (M) and convolved (Bm, unscaled) rows and where they sit
+__global__ __launch_bounds__(kThreads) void k_ats_rowstats(const double* __restrict__ M, const double* __restrict__ Bm, int npts,
+                                                           double* __restrict__ stats /*[npx][4]: mM, jM, mB, jB*/) {
+  __shared__ double red[8];
+  const int r = blockIdx.x;
+  double mm = -1e300, mb = -1e300;
+  int jm = 0, jb = 0;
+  for (int j = threadIdx.x; j < npts; j += kThreads) {
+    const double a = M[(size_t)r * npts + j], c = Bm[(size_t)r * npts + j];
+    if (a > mm) { mm = a; jm = j; }
+    if (c > mb) { mb = c; jb = j; }
+  }
+  block_argmax(mm, jm, red);
+  block_argmax(mb, jb, red);
+  if (threadIdx.x == 0) { stats[4 * r] = mm; stats[4 * r + 1] = jm; stats[4 * r + 2] = mb; stats[4 * r + 3] = jb; }
+}
+
+// reverse of k_ats_resunit (+ the scaling of k_ats_rownorm): one workgroup per output row R.  Ebar [rows][nJ] ->
+// Cbar[r][j] for the rows / columns of R's resolution units (C = Bm * sc_r); amp adjoints accumulated per row.
+__global__ __launch_bounds__(kThreads) void k_ats_resunit_adj(const double* __restrict__ Bm, const double* __restrict__ stats,
+                                                              const double* __restrict__ lam_nm, int npts, int lam_step,
+                                                              int ang_step, int row_start, const double* __restrict__ e_amps,
+                                                              double lam, double amp1, double amp2,
+                                                              const double* __restrict__ Ebar, double* __restrict__ Cbar,
+                                                              double* __restrict__ ampbar /*[rows][2]*/) {
+  __shared__ double red[8];
+  __shared__ double Dl[TSFF_NBINS];
+  const int R = blockIdx.x, nJ = npts / lam_step;
+  const int r0 = (row_start + R) * ang_step;
+  const double inv = 1.0 / (double)(ang_step * lam_step);
+  double mx = -1e300;
+  int js = 0;
+  for (int J = threadIdx.x; J < nJ; J += kThreads) {
+    double acc = 0.0;
+    for (int dr = 0; dr < ang_step; ++dr) {
+      const double sc = stats[4 * (r0 + dr)] / stats[4 * (r0 + dr) + 2];
+      for (int dj = 0; dj < lam_step; ++dj) acc += Bm[(size_t)(r0 + dr) * npts + J * lam_step + dj] * sc;
+    }
+    acc *= inv;
+    Dl[J] = acc;
+    if (acc > mx) { mx = acc; js = J; }
+  }
+  block_argmax(mx, js, red);
+  double su = 0.0, a1 = 0.0, a2 = 0.0;
+  const double ea = e_amps[R];
+  for (int J = threadIdx.x; J < nJ; J += kThreads) {
+    double lb = 0.0;
+    for (int dj = 0; dj < lam_step; ++dj) lb += lam_nm[J * lam_step + dj];
+    lb /= (double)lam_step;
+    const bool blue = lb < lam;
+    const double eb = Ebar[(size_t)R * nJ + J];
+    const double base = eb * ea * Dl[J] / mx;      // d out / d amp
+    if (blue) a1 += base; else a2 += base;
+    su += eb * ea * (blue ? amp1 : amp2) * Dl[J] / mx;   // sum_J u_J D_J, u_J = Ebar ea amp / mx
+  }
+  su = block_sum(su, red);
+  a1 = block_sum(a1, red);
+  a2 = block_sum(a2, red);
+  if (threadIdx.x == 0) { ampbar[2 * R] = a1; ampbar[2 * R + 1] = a2; }
+  for (int J = threadIdx.x; J < nJ; J += kThreads) {
+    double lb = 0.0;
+    for (int dj = 0; dj < lam_step; ++dj) lb += lam_nm[J * lam_step + dj];
+    lb /= (double)lam_step;
+    double db = Ebar[(size_t)R * nJ + J] * ea * (lb < lam ? amp1 : amp2) / mx;
+    if (J == js) db -= su / mx;
+    db *= inv;
+    for (int dr = 0; dr < ang_step; ++dr)
+      for (int dj = 0; dj < lam_step; ++dj) Cbar[(size_t)(r0 + dr) * npts + J * lam_step + dj] = db;
+  }
+}
+
+// reverse of k_ats_rownorm: C = Bm * sc, sc = mM / mB.  In place: Cbar -> Bmbar; Mbar gets the one-hot of d sc / d mM
+__global__ __launch_bounds__(kThreads) void k_ats_rownorm_adj(const double* __restrict__ Bm, const double* __restrict__ stats,
+                                                              int npts, double* __restrict__ Cbar, double* __restrict__ Mbar) {
+  __shared__ double red[8];
+  const int r = blockIdx.x;
+  const double mM = stats[4 * r], mB = stats[4 * r + 2];
+  const int jM = (int)stats[4 * r + 1], jB = (int)stats[4 * r + 3];
+  double scb = 0.0;
+  for (int j = threadIdx.x; j < npts; j += kThreads) scb += Cbar[(size_t)r * npts + j] * Bm[(size_t)r * npts + j];
+  scb = block_sum(scb, red);
+  const double sc = mM / mB;
+  for (int j = threadIdx.x; j < npts; j += kThreads) {
+    double v = Cbar[(size_t)r * npts + j] * sc;
+    if (j == jB) v -= scb * mM / (mB * mB);
+    Cbar[(size_t)r * npts + j] = v;
+    Mbar[(size_t)r * npts + j] = j == jM ? scb / mB : 0.0;
+  }
+}
+
+// reverse of k_ats_conv: Xbar[i] (+)= sum_s taps[s] Ybar[i - off - s]
+__global__ void k_ats_conv_adj(const double* __restrict__ Yb, const double* __restrict__ taps, int nt, int off, int along_rows,
+                               int npx, int npts, int accumulate, double* __restrict__ Xb) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (j >= npts) return;
+  double acc = 0.0;
+  if (along_rows) {
+    for (int s = 0; s < nt; ++s) {
+      const int rr = r - off - s;
+      if (rr >= 0 && rr < npx) acc += taps[s] * Yb[(size_t)rr * npts + j];
+    }
+  } else {
+    for (int s = 0; s < nt; ++s) {
+      const int jj = j - off - s;
+      if (jj >= 0 && jj < npts) acc += taps[s] * Yb[(size_t)r * npts + jj];
+    }
+  }
+  double* o = Xb + (size_t)r * npts + j;
+  *o = accumulate ? *o + acc : acc;
+}
+
+// reverse of k_ats_weights: Pbar[g][j][a] = filt[j] / G * sum_r Wt[r][a] Mbar[r][j]
+__global__ void k_ats_weights_adj(const double* __restrict__ Mbar, const double* __restrict__ Wt, const double* __restrict__ filt,
+                                  int G, int npts, int NA, int npx, double* __restrict__ Pbar) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (a >= NA) return;
+  double acc = 0.0;
+  for (int r = 0; r < npx; ++r) {
+    const double w = Wt[(size_t)r * NA + a];
+    if (w != 0.0) acc += w * Mbar[(size_t)r * npts + j];
+  }
+  acc *= (filt ? filt[j] : 1.0) / (double)G;
+  for (int g = 0; g < G; ++g) Pbar[((size_t)g * npts + j) * NA + a] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_fma_peak: micro-benchmark of the FP64 vector FMA rate (the roof this path is bound by): 16 independent
 // accumulators per lane, `iters` x 16 fused multiply-adds, enough wavefronts to fill every SIMD.

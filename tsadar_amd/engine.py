@@ -396,6 +396,21 @@ class Engine:
         L.check(self.lib, self.h, rc)
         return out
 
+    def ats_adjoint(self, P, e_amps, lam, amp1, amp2, Ebar):
+        """Reverse of ats_spectrum: Ebar [rows, n_lam] -> (Pbar [G, npts, n_angles] device tensor, (amp1_bar, amp2_bar))."""
+        torch = self.torch
+        Pd, Eb = self.dev(P), self.dev(Ebar)
+        ea = self.dev(np.broadcast_to(np.asarray(e_amps, dtype=np.float64).reshape(-1), (self._ats_shape[0],)).copy()
+                      if not torch.is_tensor(e_amps) else e_amps.reshape(-1))
+        assert tuple(Eb.shape) == tuple(self._ats_shape)
+        Pbar = torch.empty_like(Pd)
+        ab = (C.c_double * 2)()
+        self._sync_stream()
+        rc = self.lib.tsff_ats_adjoint(self.h, self._ptr(Pd), self._ptr(ea), float(lam), float(amp1), float(amp2), self._ptr(Eb),
+                                       self._ptr(Pbar), ab)
+        L.check(self.lib, self.h, rc)
+        return Pbar, (float(ab[0]), float(ab[1]))
+
     def forward(self, params, e_amps, i_amps, noise_e=None, noise_i=None, fe=None):
         torch = self.torch
         X = self.dev(params).reshape(-1, self.NP)
