@@ -182,6 +182,17 @@ int tsff_form_factor_2d_range(tsff_handle *h, int32_t feature, const double *phy
                               int32_t shared_fe, double ud_angle_deg, double va_angle_deg, int32_t B,
                               int64_t point_begin, int64_t point_end, double *P);
 
+/* Adjoint of tsff_form_factor_2d for ONE shared table (the 2-D path is never batched in the reference): given
+ * Pbar = d loss / d P (device, [B][G][npts][n_angles]) ->
+ *   grad_phys [B][NP] (device): d loss / d PHYSICAL parameters (Te, ne, lam, ne_gradient, Te_gradient, ud, Va, Ti, Z;
+ *     amplitudes and A carry none here), and, when grad_fe2d != NULL,
+ *   grad_fe2d [nv][nv] (device): d loss / d fe2d[i][j] -- the table adjoint of the rotate-and-project step (bicubic
+ *     weights scattered by LDS atomics, ghost cells folded back).
+ * Replaces what JAX reverse mode gives the reference for angular fits (inverse/loops.py:167-275). */
+int tsff_form_factor_2d_grad(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
+                             double ud_angle_deg, double va_angle_deg, int32_t B, const double *Pbar,
+                             double *grad_phys, double *grad_fe2d);
+
 /* Angular (ARTS) instrument chain for one image P[G][npts][n_angles] (device; from tsff_form_factor_2d or, for a 1-D
  * distribution function, tsff_form_factor): FitModel.electron_spectrum "angular_full" branch
  * (core/physics/generate_spectra.py:193-216: weight-matrix product, iawfilter), add_ATS_IRF (core/physics/irf.py:5-47,

@@ -1133,3 +1133,60 @@ def test_ats_adjoint_directional_derivatives(torch_mod, ccd, n_lam, start, end):
     h = 1e-6
     assert abs((func(Pn, a1 + h) - func(Pn, a1 - h)) / (2 * h) - a1b) < 1e-7 * abs(a1b)
     assert abs((func(Pn, a1, a2 + h) - func(Pn, a1, a2 - h)) / (2 * h) - a2b) < 1e-7 * abs(a2b)
+
+
+@pytest.mark.parametrize("nv,n_ion,G", [(48, 2, 3), (132, 1, 1)])
+def test_form_factor_2d_grad_finite_differences(torch_mod, nv, n_ion, G):
+    """Adjoint of the 2-D path (tsff_form_factor_2d_grad): J = <Pbar, P(phys, fe2d)>.  d J / d phys and d J / d fe2d[i][j]
+    against central differences of the (oracle-checked) forward tsff_form_factor_2d.  nv = 48: tables in LDS, two ion
+    species, three gradient points; nv = 132: table and its adjoint through L2 / global atomics."""
+    torch = torch_mod
+    cfg = decks.deck_fit(n_ion=n_ion)
+    if G > 1:
+        g = cfg["parameters"]["general"]
+        g["Te_gradient"].update(val=6.0, num_grad_points=G)
+        g["ne_gradient"].update(val=9.0, num_grad_points=G)
+    B = 2
+    sa = dict(sa=np.array([35.0, 60.0, 110.0]), weights=np.ones((B, 3)) / 3)
+    eng = _engine(cfg, sa)
+    normed = util.random_lineouts(cfg, B, seed=67, ranges=dict(ud=(-1.5, 1.5)))
+    phys = orc.physical_params(cfg["parameters"], normed, True)
+    phys["ud"] = np.array([0.8, -1.1])
+    X = util.normed_to_matrix(phys, n_ion)
+    _, fe2 = _fe2d(nv, "anisotropic")
+    ud_ang, va_ang = 25.0, -40.0
+    rng = np.random.default_rng(8)
+    names = ["Te", "ne", "lam", "ud", "Va", "Ti_1", "Z_1"] + (["Te_gradient", "ne_gradient", "Ti_2", "Z_2", "fract_1"] if G > 1 else [])
+    entries = [(0, 0), (0, 7), (nv - 1, nv - 1), (nv // 2, nv // 2), (nv // 2 + 3, nv // 2 - 5), (nv - 1, 3), (1, nv - 2)]
+    for feature in (0, 1):
+        P0 = eng.form_factor_2d(feature, X, fe2, ud_ang, va_ang)
+        Pbar = torch.as_tensor(rng.standard_normal(tuple(P0.shape)), device=P0.device) / P0.abs().mean()
+
+        def J(Xm, f):
+            return float((eng.form_factor_2d(feature, Xm, f, ud_ang, va_ang) * Pbar).sum())
+
+        gp, gf = eng.form_factor_2d_grad(feature, X, fe2, Pbar, ud_ang, va_ang)
+        gp, gf = gp.cpu().numpy(), gf.cpu().numpy()
+        assert np.all(np.isfinite(gp)) and np.all(np.isfinite(gf))
+        for b in range(B):
+            for nm in names:
+                s = util.slot_of(nm)
+                # the forward has kinks (linear interpolation of f1 at |xi_e| and of the Z' table): the step must keep
+                # the samples inside their cells, and lam moves omega - omega_L a million times faster than the others
+                h = (1e-10 if nm == "lam" else 1e-7) * max(abs(X[b, s]), 1e-2)
+                Xp, Xm = X.copy(), X.copy()
+                Xp[b, s] += h
+                Xm[b, s] -= h
+                fd = (J(Xp, fe2) - J(Xm, fe2)) / (2 * h)
+                scale = max(abs(fd), 1e-3 * np.max(np.abs(gp[:, s])))
+                assert abs(gp[b, s] - fd) < (2e-3 if nm == "lam" else 5e-5) * scale, (feature, b, nm, gp[b, s], fd)
+        for (i, j) in entries:
+            h = 1e-6 * fe2.max()
+            fp, fm = fe2.copy(), fe2.copy()
+            fp[i, j] += h
+            fm[i, j] -= h
+            fd = (J(X, fp) - J(X, fm)) / (2 * h)
+            assert abs(gf[i, j] - fd) < 2e-5 * max(abs(fd), 1e-4 * np.max(np.abs(gf))), (feature, i, j, gf[i, j], fd)
+        # without the table adjoint the parameter gradient is the same
+        gp2, none = eng.form_factor_2d_grad(feature, X, fe2, Pbar, ud_ang, va_ang, want_table=False)
+        assert none is None and np.allclose(gp2.cpu().numpy(), gp, rtol=1e-12, atol=0)

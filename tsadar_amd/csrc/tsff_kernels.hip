@@ -1505,6 +1505,478 @@ __global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d(KStatic S, co
 }
 
 // ------------------------------------------------------------------------------------------
+// Adjoint of k_form_factor_2d.  Same workgroup structure; per point, after the forward projection f1:
+//   one thread reverses the spectrum assembly (-> adjoints of R, fe(v_phi), dfe and of the point scalars),
+//   the group reverses ratintn, the two interpolations and the finite-difference gradient (-> f1bar[iy]),
+//   a second sampling sweep with derivative weights gives the adjoint of the rotation (cos beta, sin beta),
+//   one thread finishes the chain to the lineout scalars (LineS fields) and adds them to LBacc[b][g][:].
+// f1bar is also written to global memory for the table adjoint (k_ff2d_table_adj): the scatter into the table needs the
+// sample weights only, not the table, so it runs as a separate pass whose LDS holds the table ADJOINT.
+// ------------------------------------------------------------------------------------------
+constexpr int kNLB2 = 8;  // + 3 per ion: wpe2, wL, kL, ivTe, a_e, pref, Ud, Vd | ixi, a_i, cs
+
+// value and both first derivatives of one bicubic sample (ghost-padded table, see bicubic_sample)
+__device__ __forceinline__ void bicubic_sample_grad(const double* __restrict__ Fp, int nv, int pitch, double v0, double dv,
+                                                    double idv, double xq, double yq, double& Sx, double& Sy) {
+  int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
+  cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
+  cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
+  const double tx = (xq - (v0 + cx * dv)) * idv, ty = (yq - (v0 + cy * dv)) * idv;
+  double wx[4], wy[4], dx[4], dy[4];
+  catmull_rom(tx, wx);
+  catmull_rom(ty, wy);
+  dx[0] = -0.5 * (3.0 * tx * tx - 4.0 * tx + 1.0); dx[1] = 4.5 * tx * tx - 5.0 * tx;
+  dx[2] = -4.5 * tx * tx + 4.0 * tx + 0.5;         dx[3] = 1.5 * tx * tx - tx;
+  dy[0] = -0.5 * (3.0 * ty * ty - 4.0 * ty + 1.0); dy[1] = 4.5 * ty * ty - 5.0 * ty;
+  dy[2] = -4.5 * ty * ty + 4.0 * ty + 0.5;         dy[3] = 1.5 * ty * ty - ty;
+  const double* __restrict__ q0 = Fp + (size_t)cx * pitch + cy;
+  double sx = 0.0, sy = 0.0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double* __restrict__ row = q0 + (size_t)m * pitch;
+    const double r = wy[0] * row[0] + wy[1] * row[1] + wy[2] * row[2] + wy[3] * row[3];
+    const double rd = dy[0] * row[0] + dy[1] * row[1] + dy[2] * row[2] + dy[3] * row[3];
+    sx += dx[m] * r;
+    sy += wx[m] * rd;
+  }
+  Sx = sx * idv;
+  Sy = sy * idv;
+}
+
+template <int NI, bool LDS, int kG2>
+__global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d_adj(KStatic S, const double* __restrict__ phys,
+                                                                       const double* __restrict__ Fg, int nv, double ud_ang,
+                                                                       double va_ang, int f, long pbegin, long pend,
+                                                                       const double* __restrict__ Pbar,
+                                                                       double* __restrict__ LBacc, double* __restrict__ f1bar_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int grp = threadIdx.x >> 8, gt = threadIdx.x & (kThreads - 1);
+  const int nvp = nv <= 64 ? 64 : (nv <= 128 ? 128 : 256);
+  const int nparts = nv <= 256 ? kThreads / nvp : 1;
+  constexpr int kScA = 64;
+  const size_t gsz = (2 + (size_t)(nv <= 64 ? 4 : (nv <= 128 ? 2 : 1))) * nv + 2 * (size_t)nv + 16 + kScA;
+  double* gbase = reinterpret_cast<double*>(smem) + (size_t)grp * gsz;
+  double* f1 = gbase;              // [nv] projected distribution, later f1bar
+  double* d1 = f1 + nv;            // [nv] its gradient, later d1bar
+  double* part = d1 + nv;          // [nparts][nv] partial sums (two values per part in the derivative sweep: reused)
+  double* c0 = part + (nv <= 64 ? 4 : (nv <= 128 ? 2 : 1)) * nv;  // [nv] per-interval adjoint to d1[i]
+  double* c1 = c0 + nv;            // [nv] per-interval adjoint to d1[i + 1]
+  double* red = c1 + nv;           // [16]
+  double* sc = red + 16;           // [kScA] point scalars and adjoints
+  double* Fl = reinterpret_cast<double*>(smem) + (size_t)kG2 * gsz;
+  const int NA = S.n_angles, G = S.G, npts = S.npts;
+  constexpr int NLB = kNLB2 + 3 * NI;
+  const double dv = 12.0 / nv, v0 = -6.0 + 0.5 * dv, idv = 1.0 / dv;
+  const int pitch = pitch2d(nv, LDS);
+  if (LDS) {
+    for (int i = threadIdx.x; i < nv * nv; i += kG2 * kThreads) Fl[(i / nv + 1) * pitch + (i % nv + 1)] = Fg[i];
+    __syncthreads();
+    ghost_rows(Fl, nv, pitch, threadIdx.x, kG2 * kThreads);
+    __syncthreads();
+    ghost_cols(Fl, nv, pitch, threadIdx.x, kG2 * kThreads);
+  }
+  const double* __restrict__ F = LDS ? Fl : Fg;
+  const long stride = (long)gridDim.x * kG2;
+  for (long base = pbegin + (long)blockIdx.x * kG2; base < pend; base += stride) {
+    const long pid = base + grp;
+    const bool active = pid < pend;
+    const int a = (int)(pid % NA), j = (int)((pid / NA) % npts), g = (int)((pid / ((long)NA * npts)) % G);
+    const int b = (int)(pid / ((long)NA * npts * G));
+    __syncthreads();
+    if (active && gt == 0) {
+      Phys<NI> p;
+      load_phys<NI>(phys + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, false, p);
+      LineS<NI> L;
+      make_lines<NI>(p, S.lam_shift[f], g, G, L);
+      const double ws = S.omgs[f][j], th = S.sa_rad[a];
+      const double ks = ks_eval(ws, L.wpe2);
+      const double ct = cos(th), st = sin(th);
+      const double kx = ct * ks - L.kL, ky = st * ks;
+      const double k2 = kx * kx + ky * ky, k = sqrt(k2);
+      const double Vx = L.Vd * cos(va_ang), Vy = L.Vd * sin(va_ang);
+      const double Ux = L.Ud * cos(ud_ang), Uy = L.Ud * sin(ud_ang);
+      const double wd = (ws - L.wL) - (kx * Vx + ky * Vy);
+      const double aa = wd / k2;
+      const double xex = (aa * kx - Ux) * L.ivTe, xey = (aa * ky - Uy) * L.ivTe;
+      const double xmag = sqrt(xex * xex + xey * xey);
+      sc[0] = xex / xmag; sc[1] = xey / xmag; sc[2] = xmag;   // cos / sin of beta (atan + heaviside of :552-558)
+      sc[3] = k2; sc[4] = k; sc[5] = wd; sc[6] = ws; sc[7] = L.a_e; sc[8] = L.ivTe; sc[9] = L.wL; sc[10] = L.pref;
+      sc[11] = kx; sc[12] = ky; sc[13] = aa; sc[14] = xex; sc[15] = xey; sc[16] = ks; sc[17] = Vx; sc[18] = Vy;
+      sc[19] = Ux; sc[20] = Uy; sc[21] = ct; sc[22] = st;
+#pragma unroll
+      for (int s = 0; s < NI; ++s) { sc[24 + 3 * s] = L.ixi[s]; sc[25 + 3 * s] = L.a_i[s]; sc[26 + 3 * s] = L.cs[s]; }
+    }
+    __syncthreads();
+    const double cb = sc[0], sb = sc[1], xmag = sc[2];
+    // ---- forward projection ----
+    if (active) {
+      if (nv <= 256) {
+        const int iy = gt % nvp, pt = gt / nvp;
+        if (iy < nv) {
+          const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
+          const double y = v0 + iy * dv;
+          double acc = 0.0;
+          for (int ix = ix0; ix < ix1; ++ix) {
+            const double x = v0 + ix * dv;
+            acc += bicubic_sample(F, nv, pitch, v0, dv, idv, x * cb - y * sb, x * sb + y * cb);
+          }
+          part[pt * nv + iy] = acc;
+        }
+      } else {
+        for (int iy = gt; iy < nv; iy += kThreads) {
+          const double y = v0 + iy * dv;
+          double acc = 0.0;
+          for (int ix = 0; ix < nv; ++ix) {
+            const double x = v0 + ix * dv;
+            acc += bicubic_sample(F, nv, pitch, v0, dv, idv, x * cb - y * sb, x * sb + y * cb);
+          }
+          part[iy] = acc;
+        }
+      }
+    }
+    __syncthreads();
+    if (active)
+      for (int i = gt; i < nv; i += kThreads) {
+        double sacc = 0.0;
+        for (int q = 0; q < nparts; ++q) sacc += part[q * nv + i];
+        f1[i] = sacc * dv;
+      }
+    __syncthreads();
+    if (active)
+      for (int i = gt; i < nv; i += kThreads) {
+        double gd;
+        if (i == 0) gd = (f1[1] - f1[0]) * idv;
+        else if (i == nv - 1) gd = (f1[nv - 1] - f1[nv - 2]) * idv;
+        else gd = (f1[i + 1] - f1[i - 1]) * (0.5 * idv);
+        d1[i] = gd;
+      }
+    __syncthreads();
+    // ---- ratintn forward (value) and its partial derivatives per interval ----
+    double psum = 0.0;
+    if (active)
+      for (int i = gt; i < nv - 2; i += kThreads) {
+        const double f0 = d1[i], f1v = d1[i + 1];
+        const double g0 = (v0 + i * dv) - xmag, g1 = (v0 + (i + 1) * dv) - xmag;
+        const double fdif = f1v - f0, gdif = g1 - g0, fav = 0.5 * (f1v + f0), gav = 0.5 * (g1 + g0);
+        const double tmp = fav * gdif - gav * fdif;
+        double r, rfd, rfa, rga;   // r and dr/d(fdif, fav, gav)
+        if (fabs(gdif) < 1.0e-4 * fabs(gav)) {
+          const double ig = 1.0 / gav, c = gdif / (12.0 * gav * gav * gav);
+          r = fav * ig + tmp * c;
+          rfd = -gav * c; rfa = ig + gdif * c;
+          rga = -fav * ig * ig - fdif * c - 3.0 * tmp * c * ig;
+        } else {
+          const double lg = log(fabs((gav + 0.5 * gdif) / (gav - 0.5 * gdif))), ig2 = 1.0 / (gdif * gdif);
+          r = fdif / gdif + tmp * lg * ig2;
+          rfd = 1.0 / gdif - gav * lg * ig2;
+          rfa = gdif * lg * ig2;
+          rga = (-fdif * lg + tmp * (1.0 / (gav + 0.5 * gdif) - 1.0 / (gav - 0.5 * gdif))) * ig2;
+        }
+        psum += r * dv;
+        c0[i] = (-rfd + 0.5 * rfa) * dv;   // d(sum r dv)/d d1[i]
+        c1[i] = (rfd + 0.5 * rfa) * dv;    // d(sum r dv)/d d1[i + 1]
+        part[i] = -rga * dv;               // d(sum r dv)/d xmag   (gav = mid - xmag)
+      }
+    psum = wave_sum(psum);
+    if ((gt & 63) == 0) red[gt >> 6] = psum;
+    __syncthreads();
+    // ---- one thread: forward assembly and its reverse ----
+    if (active && gt == 0) {
+      const double R = (red[0] + red[1]) + (red[2] + red[3]);
+      const double k2 = sc[3], k = sc[4], wd = sc[5], ws = sc[6], a_e = sc[7], ivTe = sc[8], wL = sc[9], pref = sc[10];
+      double u = (xmag - v0) * idv;
+      int i = (int)u;
+      i = i < 0 ? 0 : (i > nv - 2 ? nv - 2 : i);
+      double t = (xmag - (v0 + i * dv)) * idv;
+      const bool tin = t >= 0.0 && t <= 1.0;
+      t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+      const double fe_vphi = f1[i] + t * (f1[i + 1] - f1[i]);
+      const double dfe = d1[i] + t * (d1[i + 1] - d1[i]);
+      const double ike2 = a_e / k2;
+      const double cer = -ike2 * R, cei = kPi * ike2 * dfe;
+      double cre = 0.0, cim = 0.0, gsum = 0.0;
+      const double vph = wd / k;
+      double xi[NI], zr[NI], zi[NI], dzr[NI], dzi[NI], gs[NI], iki2[NI];
+#pragma unroll
+      for (int s = 0; s < NI; ++s) {
+        xi[s] = vph * sc[24 + 3 * s];
+        ion_terms(S.zp, xi[s], zr[s], zi[s], dzr[s], dzi[s], gs[s]);
+        iki2[s] = sc[25 + 3 * s] / k2;
+        cre -= 0.5 * iki2[s] * zr[s];
+        cim -= 0.5 * iki2[s] * zi[s];
+        gsum += sc[26 + 3 * s] * gs[s];
+      }
+      const double er = 1.0 + cer + cre, ei = cei + cim;
+      const double eps2 = er * er + ei * ei, ce2 = cer * cer + cei * cei;
+      const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
+      const double N = gsum * ce2 + ci2 * fe_vphi * ivTe;
+      const double Sv = N / (k * eps2);
+      const double dop = 1.0 + 2.0 * wd / wL, Q = pref * ws * ws;
+      // reverse
+      const double Pb = Pbar[pid];
+      const double Svb = Pb * dop * Q;
+      double wdb = Pb * Sv * Q * 2.0 / wL;
+      double wLb = -Pb * Sv * Q * 2.0 * wd / (wL * wL);
+      const double prefb = Pb * Sv * dop * ws * ws;
+      const double Nb = Svb / (k * eps2);
+      double kb = -Svb * N / (k * k * eps2);
+      const double eps2b = -Svb * N / (k * eps2 * eps2);
+      const double gsumb = Nb * ce2, ce2b = Nb * gsum, ci2b = Nb * fe_vphi * ivTe;
+      const double fevb = Nb * ci2 * ivTe;
+      double ivTeb = Nb * ci2 * fe_vphi;
+      const double erb = 2.0 * er * eps2b, eib = 2.0 * ei * eps2b;
+      const double cerb = erb + 2.0 * cer * ce2b, ceib = eib + 2.0 * cei * ce2b;
+      const double creb = erb + 2.0 * (1.0 + cre) * ci2b, cimb = eib + 2.0 * cim * ci2b;
+      double ike2b = -cerb * R + ceib * kPi * dfe;
+      const double Rb = -cerb * ike2, dfeb = ceib * kPi * ike2;
+      const double a_eb = ike2b / k2;
+      double k2b = -ike2b * a_e / (k2 * k2);
+      double vphb = 0.0;
+      double* ob = sc + 44;  // adjoints of the ion scalars: [ixi, a_i, cs] per species
+#pragma unroll
+      for (int s = 0; s < NI; ++s) {
+        const double iki2b = -0.5 * (creb * zr[s] + cimb * zi[s]);
+        const double zrb = -0.5 * iki2[s] * creb, zib = -0.5 * iki2[s] * cimb;
+        const double gsb = gsumb * sc[26 + 3 * s];
+        const double xib = zrb * dzr[s] + zib * dzi[s] + gsb * gs[s] * (-2.0 * xi[s]);
+        ob[3 * s + 2] = gsumb * gs[s];            // cs
+        ob[3 * s + 1] = iki2b / k2;               // a_i
+        k2b -= iki2b * sc[25 + 3 * s] / (k2 * k2);
+        vphb += xib * sc[24 + 3 * s];
+        ob[3 * s] = xib * vph;                    // ixi
+      }
+      wdb += vphb / k;
+      kb -= vphb * wd / (k * k);
+      k2b += kb / (2.0 * k);
+      // the two interpolations at |xi_e| (jnp.interp: zero slope where clamped)
+      double xmagb = tin ? (fevb * (f1[i + 1] - f1[i]) + dfeb * (d1[i + 1] - d1[i])) * idv : 0.0;
+      sc[36] = Rb; sc[37] = fevb; sc[38] = dfeb; sc[39] = (double)i; sc[40] = t;
+      sc[41] = xmagb; sc[42] = wdb; sc[43] = wLb; sc[56] = prefb; sc[57] = ivTeb; sc[58] = a_eb; sc[59] = k2b;
+    }
+    __syncthreads();
+    // ---- group: d1bar, xmagbar (ratintn part), f1bar ----
+    double xms = 0.0;
+    if (active) {
+      const double Rb = sc[36], dfeb = sc[38], t = sc[40];
+      const int il = (int)sc[39];
+      for (int i = gt; i < nv - 2; i += kThreads) xms += part[i] * Rb;
+      for (int i = gt; i < nv; i += kThreads) {
+        double v = 0.0;
+        if (i < nv - 2) v += c0[i] * Rb;
+        if (i >= 1 && i - 1 < nv - 2) v += c1[i - 1] * Rb;
+        if (i == il) v += dfeb * (1.0 - t);
+        if (i == il + 1) v += dfeb * t;
+        c0[i] = v;   // d1bar, in place: a thread reads c0 only at its own index here, c1 is not written in this loop
+      }
+    }
+    xms = wave_sum(xms);
+    if ((gt & 63) == 0) red[8 + (gt >> 6)] = xms;
+    __syncthreads();
+    if (active) {
+      const double fevb = sc[37], t = sc[40];
+      const int il = (int)sc[39];
+      for (int i = gt; i < nv; i += kThreads) {   // gradient stencil transposed + the fe(v_phi) interpolation
+        double v = 0.0;
+        if (i + 1 <= nv - 2 && i + 1 >= 1) v -= 0.5 * idv * c0[i + 1];
+        if (i - 1 >= 1 && i - 1 <= nv - 2) v += 0.5 * idv * c0[i - 1];
+        if (i == 1) v += idv * c0[0];
+        if (i == 0) v -= idv * c0[0];
+        if (i == nv - 1) v += idv * c0[nv - 1];
+        if (i == nv - 2) v -= idv * c0[nv - 1];
+        if (i == il) v += fevb * (1.0 - t);
+        if (i == il + 1) v += fevb * t;
+        c1[i] = v;   // f1bar
+      }
+    }
+    __syncthreads();
+    if (active && f1bar_out)
+    {
+      for (int i = gt; i < nv; i += kThreads) f1bar_out[(size_t)(pid - pbegin) * (nv + 2) + i] = c1[i];
+      if (gt == 0) { f1bar_out[(size_t)(pid - pbegin) * (nv + 2) + nv] = cb; f1bar_out[(size_t)(pid - pbegin) * (nv + 2) + nv + 1] = sb; }
+    }
+    // ---- derivative sampling sweep: adjoint of (cos beta, sin beta) ----
+    double acb = 0.0, asb = 0.0;
+    if (active) {
+      if (nv <= 256) {
+        const int iy = gt % nvp, pt = gt / nvp;
+        if (iy < nv) {
+          const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
+          const double y = v0 + iy * dv;
+          double s1 = 0.0, s2 = 0.0;
+          for (int ix = ix0; ix < ix1; ++ix) {
+            const double x = v0 + ix * dv;
+            double Sx, Sy;
+            bicubic_sample_grad(F, nv, pitch, v0, dv, idv, x * cb - y * sb, x * sb + y * cb, Sx, Sy);
+            s1 += Sx * x + Sy * y;
+            s2 += -Sx * y + Sy * x;
+          }
+          acb = s1 * c1[iy] * dv;
+          asb = s2 * c1[iy] * dv;
+        }
+      } else {
+        for (int iy = gt; iy < nv; iy += kThreads) {
+          const double y = v0 + iy * dv;
+          double s1 = 0.0, s2 = 0.0;
+          for (int ix = 0; ix < nv; ++ix) {
+            const double x = v0 + ix * dv;
+            double Sx, Sy;
+            bicubic_sample_grad(F, nv, pitch, v0, dv, idv, x * cb - y * sb, x * sb + y * cb, Sx, Sy);
+            s1 += Sx * x + Sy * y;
+            s2 += -Sx * y + Sy * x;
+          }
+          acb += s1 * c1[iy] * dv;
+          asb += s2 * c1[iy] * dv;
+        }
+      }
+    }
+    acb = wave_sum(acb);
+    asb = wave_sum(asb);
+    if ((gt & 63) == 0) { red[gt >> 6] = acb; red[4 + (gt >> 6)] = asb; }
+    __syncthreads();
+    // ---- one thread: chain to the lineout scalars ----
+    if (active && gt == 0) {
+      const double cbb = (red[0] + red[1]) + (red[2] + red[3]), sbb = (red[4] + red[5]) + (red[6] + red[7]);
+      double xmagb = sc[41] + (red[8] + red[9]) + (red[10] + red[11]);
+      double wdb = sc[42], wLb = sc[43], ivTeb = sc[57], k2b = sc[59];
+      const double prefb = sc[56], a_eb = sc[58];
+      const double k2 = sc[3], wd = sc[5], ivTe = sc[8], kx = sc[11], ky = sc[12], aa = sc[13], xex = sc[14], xey = sc[15];
+      const double ks = sc[16], Vx = sc[17], Vy = sc[18], Ux = sc[19], Uy = sc[20], ct = sc[21], st = sc[22];
+      // cb = xex / xmag, sb = xey / xmag, xmag = |(xex, xey)|
+      const double xm = sc[2];
+      const double xmt = xmagb - (cbb * xex + sbb * xey) / (xm * xm);
+      const double xexb = cbb / xm + xmt * xex / xm, xeyb = sbb / xm + xmt * xey / xm;
+      // xex = (aa kx - Ux) ivTe
+      double aab = (xexb * kx + xeyb * ky) * ivTe;
+      double kxb = xexb * aa * ivTe, kyb = xeyb * aa * ivTe;
+      const double Uxb = -xexb * ivTe, Uyb = -xeyb * ivTe;
+      ivTeb += xexb * (aa * kx - Ux) + xeyb * (aa * ky - Uy);
+      // aa = wd / k2
+      wdb += aab / k2;
+      k2b -= aab * wd / (k2 * k2);
+      // wd = ws - wL - (kx Vx + ky Vy)
+      wLb -= wdb;
+      kxb -= wdb * Vx; kyb -= wdb * Vy;
+      const double Vxb = -wdb * kx, Vyb = -wdb * ky;
+      // k2 = kx^2 + ky^2
+      kxb += 2.0 * kx * k2b; kyb += 2.0 * ky * k2b;
+      // kx = ct ks - kL, ky = st ks
+      const double ksb = ct * kxb + st * kyb;
+      const double kLb = -kxb;
+      const double wpe2b = -ksb / (2.0 * kC * kC * ks);
+      const double Vdb = Vxb * cos(va_ang) + Vyb * sin(va_ang);
+      const double Udb = Uxb * cos(ud_ang) + Uyb * sin(ud_ang);
+      double* o = LBacc + ((size_t)b * G + g) * NLB;
+      atomicAdd(o + 0, wpe2b); atomicAdd(o + 1, wLb); atomicAdd(o + 2, kLb); atomicAdd(o + 3, ivTeb);
+      atomicAdd(o + 4, a_eb); atomicAdd(o + 5, prefb); atomicAdd(o + 6, Udb); atomicAdd(o + 7, Vdb);
+#pragma unroll
+      for (int s = 0; s < NI; ++s) {
+        atomicAdd(o + 8 + 3 * s, sc[44 + 3 * s]); atomicAdd(o + 9 + 3 * s, sc[45 + 3 * s]); atomicAdd(o + 10 + 3 * s, sc[46 + 3 * s]);
+      }
+    }
+  }
+}
+
+// Table adjoint: Fbar[cell entries] += f1bar[point][iy] dv wx[m] wy[n] for every sample of every point.  The scatter needs
+// the sample weights only, so the LDS of this pass holds the padded table ADJOINT (LDS atomics, ds_add_f64); each
+// persistent workgroup adds its partial table to the global one at the end.  LDSV = false (tables that do not fit):
+// global atomics straight into the padded adjoint.
+template <bool LDSV>
+__global__ __launch_bounds__(4 * kThreads) void k_ff2d_table_adj(int nv, const double* __restrict__ f1bar, long npoint,
+                                                                  double* __restrict__ Fbar_pad) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* Tl = reinterpret_cast<double*>(smem);
+  const int pitch = LDSV ? pitch2d(nv, true) : nv + 2;
+  if (LDSV) {
+    for (int i = threadIdx.x; i < (nv + 2) * pitch; i += blockDim.x) Tl[i] = 0.0;
+    __syncthreads();
+  }
+  double* __restrict__ T = LDSV ? Tl : Fbar_pad;
+  const double dv = 12.0 / nv, v0 = -6.0 + 0.5 * dv, idv = 1.0 / dv;
+  const int grp = threadIdx.x >> 8, gt = threadIdx.x & (kThreads - 1);
+  const int nvp = nv <= 64 ? 64 : (nv <= 128 ? 128 : 256);
+  const int nparts = nv <= 256 ? kThreads / nvp : 1;
+  for (long pid = (long)blockIdx.x * 4 + grp; pid < npoint; pid += (long)gridDim.x * 4) {
+    const double* fb = f1bar + (size_t)pid * (nv + 2);
+    const double cb = fb[nv], sb = fb[nv + 1];
+    for (int iy0 = gt % nvp; iy0 < nv; iy0 += (nv <= 256 ? nv : kThreads)) {
+      const int iy = iy0, pt = nv <= 256 ? gt / nvp : 0;
+      const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
+      const double y = v0 + iy * dv, val = fb[iy] * dv;
+      for (int ix = ix0; ix < ix1; ++ix) {
+        const double x = v0 + ix * dv;
+        const double xq = x * cb - y * sb, yq = x * sb + y * cb;
+        int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
+        cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
+        cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
+        double wx[4], wy[4];
+        catmull_rom((xq - (v0 + cx * dv)) * idv, wx);
+        catmull_rom((yq - (v0 + cy * dv)) * idv, wy);
+        double* q0 = T + (size_t)cx * pitch + cy;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const double wm = val * wx[m];
+#pragma unroll
+          for (int n = 0; n < 4; ++n) atomicAdd(q0 + (size_t)m * pitch + n, wm * wy[n]);
+        }
+      }
+      if (nv <= 256) break;
+    }
+  }
+  if (LDSV) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < (nv + 2) * (nv + 2); i += blockDim.x) {
+      const int r = i / (nv + 2), c = i % (nv + 2);
+      const double v = Tl[r * pitch + c];
+      if (v != 0.0) atomicAdd(Fbar_pad + i, v);
+    }
+  }
+}
+
+// adjoint of the ghost cells (ghost_cols was applied last, so it is reversed first), then the interior is copied out
+__global__ __launch_bounds__(kThreads) void k_ff2d_fold_ghosts(int nv, double* __restrict__ P, double* __restrict__ out) {
+  const int pitch = nv + 2;
+  for (int r = threadIdx.x; r < nv + 2; r += kThreads) {
+    double* row = P + (size_t)r * pitch;
+    row[1] += 2.0 * row[0]; row[2] -= row[0];
+    row[nv] += 2.0 * row[nv + 1]; row[nv - 1] -= row[nv + 1];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < nv; c += kThreads) {
+    P[pitch + c + 1] += 2.0 * P[c + 1]; P[2 * pitch + c + 1] -= P[c + 1];
+    P[(size_t)nv * pitch + c + 1] += 2.0 * P[(size_t)(nv + 1) * pitch + c + 1];
+    P[(size_t)(nv - 1) * pitch + c + 1] -= P[(size_t)(nv + 1) * pitch + c + 1];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nv * nv; i += kThreads) out[i] = P[(size_t)(i / nv + 1) * pitch + (i % nv + 1)];
+}
+
+// LBacc[b][g][NLB] -> gphys[b][NP]: make_lines_adjoint per gradient point, summed (one thread per lineout)
+template <int NI>
+__global__ void k_ff2d_lines_adj(KStatic S, const double* __restrict__ phys, int f, int B, const double* __restrict__ LBacc,
+                                 double* __restrict__ gphys) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  constexpr int NPk = TSFF_NP(NI), NLB = kNLB2 + 3 * NI;
+  Phys<NI> p;
+  load_phys<NI>(phys + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, false, p);
+  double pb[NPk];
+#pragma unroll
+  for (int s = 0; s < NPk; ++s) pb[s] = 0.0;
+  for (int g = 0; g < S.G; ++g) {
+    LineS<NI> L, LB;
+    make_lines<NI>(p, S.lam_shift[f], g, S.G, L);
+    zero_lines<NI>(LB);
+    const double* o = LBacc + ((size_t)b * S.G + g) * NLB;
+    LB.wpe2 = o[0]; LB.wL = o[1]; LB.kL = o[2]; LB.ivTe = o[3]; LB.a_e = o[4]; LB.pref = o[5]; LB.Ud = o[6]; LB.Vd = o[7];
+#pragma unroll
+    for (int s = 0; s < NI; ++s) { LB.ixi[s] = o[8 + 3 * s]; LB.a_i[s] = o[9 + 3 * s]; LB.cs[s] = o[10 + 3 * s]; }
+    make_lines_adjoint<NI>(p, S.lam_shift[f], g, S.G, L, LB, pb);
+  }
+#pragma unroll
+  for (int s = 0; s < NPk; ++s) gphys[(size_t)b * NPk + s] = pb[s];
+}
+
+// ------------------------------------------------------------------------------------------
 // Angular (ARTS) instrument chain: FitModel.electron_spectrum for spectype "angular_full"
 // (generate_spectra.py:193-216), add_ATS_IRF (irf.py:5-47), reduce_ATS_to_resunit
 // (thomson_diagnostic.py:78-107).  Five small kernels over [n_px x npts] images; none of them is hot.

@@ -357,6 +357,23 @@ class Engine:
         L.check(self.lib, self.h, rc)
         return P
 
+    def form_factor_2d_grad(self, feature, phys, fe2d, Pbar, ud_angle=0.0, va_angle=0.0, want_table=True):
+        """Adjoint of form_factor_2d (one shared table): Pbar [B, G, npts, n_angles] ->
+        (grad_phys [B, NP], grad_fe2d [nv, nv] or None) as device tensors."""
+        torch = self.torch
+        phys_d = self.dev(phys).reshape(-1, self.NP)
+        B = phys_d.shape[0]
+        fe_d, Pb = self.dev(fe2d), self.dev(Pbar)
+        assert fe_d.dim() == 2 and fe_d.shape[0] == fe_d.shape[1]
+        nv = int(fe_d.shape[0])
+        gp = torch.empty((B, self.NP), dtype=torch.float64, device=self.device)
+        gf = torch.empty((nv, nv), dtype=torch.float64, device=self.device) if want_table else None
+        self._sync_stream()
+        rc = self.lib.tsff_form_factor_2d_grad(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, float(ud_angle),
+                                               float(va_angle), B, self._ptr(Pb), self._ptr(gp), self._ptr(gf))
+        L.check(self.lib, self.h, rc)
+        return gp, gf
+
     def ats_setup(self, weights, ang_axis, stddev_lam, stddev_ang, lam_step=1, ang_step=1, row_start=0, row_end=None,
                   irf_cutoff_sigmas=12.0):
         """Static configuration of the angular (ARTS) instrument chain: weight matrix [n_px, n_angles], the calibrated
