@@ -27,3 +27,13 @@ for nv, na in ((128, 241), (256, 512)):
     dt = time.perf_counter() - t0
     npt = 1024 * na
     print(f"nv {nv} angles {na}: {dt*1e3:.1f} ms per EPW image ({npt} points, {npt*nv*nv/dt/1e9:.1f} G bicubic evaluations/s), finite {bool(torch.isfinite(P).all())}")
+    Pbar = torch.randn_like(P)
+    for want_table in (False, True):
+        eng.form_factor_2d_grad(0, tp.physical_matrix(), fd, Pbar, 10.0, 20.0, want_table=want_table)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gp, gf = eng.form_factor_2d_grad(0, tp.physical_matrix(), fd, Pbar, 10.0, 20.0, want_table=want_table)
+        torch.cuda.synchronize()
+        da = time.perf_counter() - t0
+        print(f"   adjoint (table adjoint {want_table}): {da*1e3:.1f} ms = {da/dt:.2f} forwards, finite "
+              f"{bool(torch.isfinite(gp).all()) and (gf is None or bool(torch.isfinite(gf).all()))}", flush=True)

@@ -1190,3 +1190,87 @@ def test_form_factor_2d_grad_finite_differences(torch_mod, nv, n_ion, G):
         # without the table adjoint the parameter gradient is the same
         gp2, none = eng.form_factor_2d_grad(feature, X, fe2, Pbar, ud_ang, va_ang, want_table=False)
         assert none is None and np.allclose(gp2.cpu().numpy(), gp, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("fe_type", ["arbitrary", "sphericalharmonic"])
+def test_angular_2d_vg_loss_adjoint(torch_mod, fe_type):
+    """LossFunction.vg_loss for an ARTS deck with a 2-D distribution function: the gradient comes from the hand-written
+    adjoint (loss seed -> tsff_ats_adjoint -> tsff_form_factor_2d_grad -> parameter transform / table generator) and is
+    compared leaf by leaf with central differences of the loss value (full GPU forwards): plasma parameters, the two
+    drift speeds, amplitudes, and the distribution function itself -- all nvx^2 values of Arbitrary2V.fval in one
+    evaluation, or the three Mora-Yahi generator parameters."""
+    from tsadar_amd import ThomsonParams, tree
+    from tsadar_amd.loss_function import LossFunction
+
+    nvx = 48
+    cfg = decks.deck_angular(2, nvx, (128, 256), 10, 110)
+    if fe_type == "sphericalharmonic":
+        cfg["parameters"]["electron"]["fe"] = {"active": True, "dim": 2, "type": "sphericalharmonic", "nvx": nvx, "params": {
+            "flm_type": "mora-yahi", "init_m": 2.2, "LTx": 225000.0, "LTy": 400000.0, "Nl": 1, "nvr": 64}}
+    g = cfg["parameters"]["general"]
+    for k, val in (("ud", 0.6), ("Va", -0.8)):
+        g[k]["val"], g[k]["active"] = val, True
+    g["amp2"]["active"] = True
+    sa = _angular_sa(cfg)
+    # data: the model itself at a different plasma condition
+    tp = ThomsonParams(cfg["parameters"], 1, batch=False, activate=True)
+    truth = tp.copy()
+    truth.X[0, L.P_TE] -= 0.3
+    truth.X[0, L.P_NE] += 0.25
+    batch = dict(e_data=np.ones((100, 256)), i_data=np.zeros((100, 256)), e_amps=np.ones((100, 1)), i_amps=np.zeros(100),
+                 noise_e=np.array([0.0]), noise_i=np.array([0.0]))
+    loss_fn = LossFunction(cfg, sa, batch)
+    data = loss_fn.ts_diag(truth, batch)[0]
+    batch["e_data"] = data
+    loss_fn = LossFunction(cfg, sa, batch)
+    spec = tree.get_filter_spec(cfg["parameters"], tp)
+    names = [n for n, _ in spec]
+    assert ("electron", "fval" if fe_type == "arbitrary" else "fe") in names and ("general", "ud") in names
+    diff, static = tree.partition(tp, spec)
+    x0, loss_fn.unravel_weights = tree.ravel_pytree(diff)
+    assert x0.size == len(spec) - 1 + (nvx * nvx if fe_type == "arbitrary" else 3)
+    val, gflat = loss_fn.vg_loss(x0, static, batch)
+    assert np.isfinite(val) and val > 0 and gflat.shape == x0.shape and np.all(np.isfinite(gflat))
+    grads = diff.like(gflat)
+
+    def value(x):
+        return loss_fn._angular_value(tree.combine(static, diff.like(x)), batch)[0]
+
+    assert abs(value(x0) - val) < 1e-13 * val
+    o = 0
+    rng = np.random.default_rng(4)
+    for (name, s), v in zip(diff.slots, diff.values):
+        gl = gflat[o:o + v.size]
+        if v.size > 8:   # the free-form table: a few single entries and one random direction through all of them
+            fv = v.ravel()
+            cand = np.argsort(-np.abs(gl))[:3].tolist() + [int(rng.integers(v.size)) for _ in range(2)]
+            for i in cand:
+                h = 1e-6 * max(abs(fv[i]), 1.0)
+                e = np.zeros_like(x0)
+                e[o + i] = h
+                fd = (value(x0 + e) - value(x0 - e)) / (2 * h)
+                assert abs(gl[i] - fd) < 1e-4 * max(abs(fd), 1e-3 * np.max(np.abs(gl))), (name, i, gl[i], fd)
+            d = np.zeros_like(x0)
+            d[o:o + v.size] = rng.standard_normal(v.size)
+            h = 1e-7
+            fd = (value(x0 + h * d) - value(x0 - h * d)) / (2 * h)
+            assert abs(np.dot(gflat, d) - fd) < 1e-4 * abs(fd), (name, np.dot(gflat, d), fd)
+        else:
+            for i in range(v.size):
+                h = 1e-9 if name[1] == "lam" else 1e-6   # (lam: see test_form_factor_2d_grad_finite_differences)
+                e = np.zeros_like(x0)
+                e[o + i] = h
+                fd = (value(x0 + e) - value(x0 - e)) / (2 * h)
+                tol = 5e-3 if name[1] == "lam" else 2e-4
+                assert abs(gl[i] - fd) < tol * max(abs(fd), 1e-4 * np.max(np.abs(gflat))), (name, i, gl[i], fd)
+        o += v.size
+    # the finite-difference fallback (force_fd) agrees on the scalar leaves
+    if fe_type == "sphericalharmonic":
+        loss_fn.force_fd = True
+        v2, g2 = loss_fn.vg_loss(x0, static, batch)
+        loss_fn.force_fd = False
+        assert v2 == val
+        lam_i = names.index(("general", "lam"))
+        keep = np.ones(x0.size, bool)
+        keep[lam_i if lam_i < names.index(("electron", "fe")) else lam_i + 2] = False
+        assert np.max(np.abs(g2 - gflat)[keep]) < 2e-3 * np.max(np.abs(gflat[keep])), (g2, gflat)

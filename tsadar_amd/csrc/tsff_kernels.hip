@@ -1878,19 +1878,35 @@ __global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d_adj(KStatic S
 
 // Table adjoint: Fbar[cell entries] += f1bar[point][iy] dv wx[m] wy[n] for every sample of every point.  The scatter needs
 // the sample weights only, so the LDS of this pass holds the padded table ADJOINT (LDS atomics, ds_add_f64); each
-// persistent workgroup adds its partial table to the global one at the end.  LDSV = false (tables that do not fit):
-// global atomics straight into the padded adjoint.
-template <bool LDSV>
+// persistent workgroup adds its partial table to the global one at the end.  Tables larger than LDS are cut into tiles
+// of kTile2 x kTile2 cells (blockIdx.y = tile; a tile of cells touches (kTile2 + 3)^2 padded entries): the workgroups
+// of a tile walk ALL points but visit only the samples whose cell lies in their tile -- per column iy that is one
+// contiguous run of ix, found from the intersection of the rotated line with the tile rectangle (taken two samples
+// wide on each side and then decided per sample by the very floor() every tile evaluates, so that each sample lands in
+// exactly one tile).
+constexpr int kTile2 = 128;
+// indices ix with lo <= c * ix + e < hi (lo_inf / hi_inf: that side is open), widened by two
+__device__ __forceinline__ void line_range(double c, double e, double lo, double hi, bool lo_inf, bool hi_inf, int& a, int& b) {
+  if (fabs(c) < 1.0e-9) return;   // (almost) parallel to the tile edge: the per-sample test decides
+  double x0 = lo_inf ? -1.0e9 : (lo - e) / c, x1 = hi_inf ? 1.0e9 : (hi - e) / c;
+  if (c < 0.0) { const double t = x0; x0 = x1; x1 = t; if (lo_inf) x1 = 1.0e9; if (hi_inf) x0 = -1.0e9; }
+  x0 = fmin(fmax(x0, -1.0e9), 1.0e9);
+  x1 = fmin(fmax(x1, -1.0e9), 1.0e9);
+  const int ia = (int)floor(x0) - 2, ib = (int)ceil(x1) + 2;
+  a = a > ia ? a : ia;
+  b = b < ib ? b : ib;
+}
 __global__ __launch_bounds__(4 * kThreads) void k_ff2d_table_adj(int nv, const double* __restrict__ f1bar, long npoint,
                                                                   double* __restrict__ Fbar_pad) {
   extern __shared__ __align__(16) unsigned char smem[];
-  double* Tl = reinterpret_cast<double*>(smem);
-  const int pitch = LDSV ? pitch2d(nv, true) : nv + 2;
-  if (LDSV) {
-    for (int i = threadIdx.x; i < (nv + 2) * pitch; i += blockDim.x) Tl[i] = 0.0;
-    __syncthreads();
-  }
-  double* __restrict__ T = LDSV ? Tl : Fbar_pad;
+  double* T = reinterpret_cast<double*>(smem);
+  const int ncell = nv - 1, ntx = (ncell + kTile2 - 1) / kTile2;
+  const int cx0 = (blockIdx.y / ntx) * kTile2, cy0 = (blockIdx.y % ntx) * kTile2;
+  const int cx1 = cx0 + kTile2 < ncell ? cx0 + kTile2 : ncell, cy1 = cy0 + kTile2 < ncell ? cy0 + kTile2 : ncell;
+  const int trow = cx1 - cx0 + 3, tcol = cy1 - cy0 + 3, pitch = tcol | 1;
+  const bool whole = ntx == 1;
+  for (int i = threadIdx.x; i < trow * pitch; i += blockDim.x) T[i] = 0.0;
+  __syncthreads();
   const double dv = 12.0 / nv, v0 = -6.0 + 0.5 * dv, idv = 1.0 / dv;
   const int grp = threadIdx.x >> 8, gt = threadIdx.x & (kThreads - 1);
   const int nvp = nv <= 64 ? 64 : (nv <= 128 ? 128 : 256);
@@ -1898,20 +1914,26 @@ __global__ __launch_bounds__(4 * kThreads) void k_ff2d_table_adj(int nv, const d
   for (long pid = (long)blockIdx.x * 4 + grp; pid < npoint; pid += (long)gridDim.x * 4) {
     const double* fb = f1bar + (size_t)pid * (nv + 2);
     const double cb = fb[nv], sb = fb[nv + 1];
-    for (int iy0 = gt % nvp; iy0 < nv; iy0 += (nv <= 256 ? nv : kThreads)) {
-      const int iy = iy0, pt = nv <= 256 ? gt / nvp : 0;
-      const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
+    for (int iy = nv <= 256 ? gt % nvp : gt; iy < nv; iy += kThreads) {
+      const int pt = nv <= 256 ? gt / nvp : 0;
+      int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
       const double y = v0 + iy * dv, val = fb[iy] * dv;
+      if (!whole) {
+        // cell coordinate of sample ix along each table axis: u = c * ix + e
+        line_range(cb, (cb * v0 - y * sb - v0) * idv, (double)cx0, (double)cx1, cx0 == 0, cx1 == ncell, ix0, ix1);
+        line_range(sb, (sb * v0 + y * cb - v0) * idv, (double)cy0, (double)cy1, cy0 == 0, cy1 == ncell, ix0, ix1);
+      }
       for (int ix = ix0; ix < ix1; ++ix) {
         const double x = v0 + ix * dv;
         const double xq = x * cb - y * sb, yq = x * sb + y * cb;
         int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
         cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
         cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
+        if (!whole && (cx < cx0 || cx >= cx1 || cy < cy0 || cy >= cy1)) continue;
         double wx[4], wy[4];
         catmull_rom((xq - (v0 + cx * dv)) * idv, wx);
         catmull_rom((yq - (v0 + cy * dv)) * idv, wy);
-        double* q0 = T + (size_t)cx * pitch + cy;
+        double* q0 = T + (size_t)(cx - cx0) * pitch + (cy - cy0);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const double wm = val * wx[m];
@@ -1922,13 +1944,11 @@ __global__ __launch_bounds__(4 * kThreads) void k_ff2d_table_adj(int nv, const d
       if (nv <= 256) break;
     }
   }
-  if (LDSV) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < (nv + 2) * (nv + 2); i += blockDim.x) {
-      const int r = i / (nv + 2), c = i % (nv + 2);
-      const double v = Tl[r * pitch + c];
-      if (v != 0.0) atomicAdd(Fbar_pad + i, v);
-    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < trow * tcol; i += blockDim.x) {
+    const int r = i / tcol, c = i % tcol;
+    const double v = T[r * pitch + c];
+    if (v != 0.0) atomicAdd(Fbar_pad + (size_t)(cx0 + r) * (nv + 2) + (cy0 + c), v);
   }
 }
 

@@ -72,9 +72,10 @@ class ThomsonScatteringDiagnostic:
                           min(cfg["data"]["lineouts"]["end"], n_px // ang_step), self.irf_cutoff_sigmas)
             eng._ats_key = key
         phys = ts_params.physical_matrix()
+        fe2 = None
         if eng.fe_dim == 2:
             gen = cfg["parameters"]["general"]
-            fe2 = ts_params()["electron"]["fe"]
+            fe2 = eng.dev(np.ascontiguousarray(ts_params()["electron"]["fe"], dtype=np.float64))
             P = eng.form_factor_2d(0, phys, fe2, gen["ud"]["angle"], gen["Va"]["angle"])
         else:
             P = eng.form_factor(0, phys, np.asarray(ts_params()["electron"]["fe"]).reshape(1, -1))
@@ -84,6 +85,8 @@ class ThomsonScatteringDiagnostic:
         E = eng.ats_spectrum(P[0], e_amps, p[L.P_LAM], p[L.P_AMP1], p[L.P_AMP2]).cpu().numpy()
         E = E + np.asarray(batch["noise_e"])
         lamE = np.mean(wavelength_axis_nm(cfg["other"]["lamrangE"], eng.npts).reshape(-1, lam_step), axis=1)
+        # what the adjoint (LossFunction._vg_angular) needs again: the device-resident P, the table and the parameters
+        self._angular_ctx = dict(P=P, phys=phys, fe2=fe2, e_amps=e_amps)
         return E, 0 + np.asarray(batch["noise_i"]), lamE, []
 
     def spectrum_breakdown(self, ts_params, batch):

@@ -86,6 +86,22 @@ def arbitrary_2v(fval: np.ndarray, learn_log: bool) -> np.ndarray:
     return f / np.sum(f) / (vx[1] - vx[0]) ** 2.0
 
 
+def arbitrary_2v_vjp(fval: np.ndarray, learn_log: bool, fe_bar: np.ndarray) -> np.ndarray:
+    """Transpose of the Jacobian of :func:`arbitrary_2v`: d loss / d f_e[nvx, nvx] -> d loss / d fval[nvx, nvx]."""
+    nvx = fval.shape[-1]
+    vx = velocity_grid(nvx)
+    c = 1.0 / (vx[1] - vx[0]) ** 2.0
+    fv = np.asarray(fval, dtype=np.float64)
+    f = fv**2.0
+    if learn_log:
+        f = np.power(10.0, -f)
+    tot = np.sum(f)
+    f_bar = c * (fe_bar / tot - np.sum(fe_bar * f) / tot**2)  # F = c f / sum f
+    if learn_log:
+        return f_bar * (-np.log(10.0) * f) * 2.0 * fv
+    return f_bar * 2.0 * fv
+
+
 # ---------------------------------------------------------------------------------------------
 # SphericalHarmonics (spherical_harmonics.py:150-318): f(vx, vy) = f00(|v|) + sum_{l<=Nl, m<=l} f_lm(|v|) Re Y_l^m.
 # The reference evaluates jax.scipy.special.sph_harm(m, l, azimuth = arccos(vy/|vy|), polar = arctan2(vy, vx)); with
@@ -165,6 +181,23 @@ class SphericalHarmonics:
                 prm["flm_sign"] = vec[o : o + n].copy(); o += n
                 prm["flm_mag"] = vec[o : o + n].copy(); o += n
         self.normed_m = float(vec[o])
+
+    def vjp(self, fe_bar: np.ndarray, step: float = 1e-6) -> np.ndarray:
+        """d loss / d f_e[nvx, nvx] -> d loss / d get_params(): the generator is a cheap host function of a few
+        parameters, its Jacobian is taken by central differences (2 evaluations per parameter) and contracted with the
+        table adjoint that the GPU delivers."""
+        theta = self.get_params()
+        out = np.zeros_like(theta)
+        for i in range(theta.size):
+            vals = []
+            for sgn in (+1.0, -1.0):
+                t = theta.copy()
+                t[i] += sgn * step
+                self.set_params(t)
+                vals.append(self())
+            out[i] = np.sum(fe_bar * (vals[0] - vals[1])) / (2.0 * step)
+        self.set_params(theta)
+        return out
 
     def get_unnormed_m(self) -> float:
         return 1.0 / (1.0 + np.exp(-self.normed_m)) * self.m_scale + self.m_shift

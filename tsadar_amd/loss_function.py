@@ -35,7 +35,8 @@ class LossFunction:
         self.angular = "angular" in cfg["other"]["extraoptions"]["spectype"]
         if self.angular and distributed:
             raise NotImplementedError("angular fits evaluate one plasma condition: nothing to shard over lineouts")
-        self.fd_step = 1e-5  # normalised units; central differences of the angular model (see _vg_angular)
+        self.fd_step = 1e-5  # normalised units; central differences of the 1-D angular model (see _vg_angular)
+        self.force_fd = False  # True: central differences for 2-D distribution functions too (cross-check of the adjoint)
         self.ts_diag = ThomsonScatteringDiagnostic(cfg, scattering_angles=scattering_angles)
         self.distributed = distributed
         self.pg = process_group
@@ -89,10 +90,10 @@ class LossFunction:
         return eng, w, terms, grad, E, I
 
     # ---- angular (ARTS) decks ------------------------------------------------------------------
-    def _angular_value(self, ts_params: ThomsonParams, batch):
+    def _angular_value(self, ts_params: ThomsonParams, batch, want_bar=False):
         """calc_loss / calc_ei_error for one ARTS image (loss_function.py:190-267, 269-341, 364-373): the electron
         feature only (ARTS measures no ion feature), masks on the resolution-unit wavelength axis, nanmean over the
-        whole image, (blue + red) / 2."""
+        whole image, (blue + red) / 2.  want_bar: also d value / d ThryE (the seed of the adjoint)."""
         E, _, lamE, _ = self.ts_diag(ts_params, batch)
         d = np.asarray(batch["e_data"], dtype=np.float64)
         method = self.cfg["optimizer"]["loss_method"]
@@ -107,24 +108,44 @@ class LossFunction:
             err = E - d * np.log(E)
         ext, r = self.cfg["other"]["extraoptions"], self.cfg["data"]["fit_rng"]
         e_error = 0.0
+        wcol = np.zeros(E.shape[1])  # d e_error / d err[:, j] (the same for every row)
         if ext["fit_EPWb"]:
-            e_error += float(np.mean(err[:, (lamE > r["blue_min"]) & (lamE < r["blue_max"])]))
+            blue = (lamE > r["blue_min"]) & (lamE < r["blue_max"])
+            e_error += float(np.mean(err[:, blue]))
+            wcol[blue] += 1.0 / (E.shape[0] * max(int(blue.sum()), 1))
         if ext["fit_EPWr"]:
-            e_error += float(np.mean(err[:, (lamE > r["red_min"]) & (lamE < r["red_max"])]))
+            red = (lamE > r["red_min"]) & (lamE < r["red_max"])
+            e_error += float(np.mean(err[:, red]))
+            wcol[red] += 1.0 / (E.shape[0] * max(int(red.sum()), 1))
             if ext["fit_EPWb"]:
                 e_error *= 0.5
-        return e_error, E
+                wcol *= 0.5
+        if not want_bar:
+            return e_error, E
+        if method == "l1":
+            derr = -np.sign(d - E) / un
+        elif method == "l2":
+            derr = -2.0 * (d - E) / un
+        elif method == "log-cosh":
+            derr = -np.tanh(d - E)
+        else:
+            derr = 1.0 - d / E
+        return e_error, E, derr * wcol[None, :]
 
     def _vg_angular(self, diff_weights, static_weights, batch):
-        """Value and gradient of the angular model.  The reference differentiates its JAX model; the MI355X path has no
-        adjoint of the 2-D form factor yet, so the gradient is a central difference over the trainable scalar leaves
-        (2 P full forward evaluations of the image: P ~ 6, 23 ms each at the ARTS size), step ``fd_step`` in
-        normalised units.  Accuracy is that of the difference quotient (~1e-6 relative), not of autodiff."""
+        """Value and gradient of the angular model.  2-D distribution functions (the expensive case: one rotated
+        projection of the table per (wavelength, angle) point) go through the hand-written adjoint -- loss seed ->
+        tsff_ats_adjoint -> tsff_form_factor_2d_grad -> chain rule of the parameter transform and of the table
+        generator -- at the cost of about three forward evaluations whatever the number of parameters, which is what
+        reverse-mode JAX gives the reference (loops.py:167-275).  1-D distribution functions (1 ms forwards) keep the
+        central difference over the trainable scalar leaves, step ``fd_step`` in normalised units."""
         ts_params = tree.combine(static_weights, diff_weights)
+        if ts_params.fe_dim == 2 and not getattr(self, "force_fd", False):
+            return self._vg_angular_adjoint(ts_params, diff_weights, batch)
         value, E = self._angular_value(ts_params, batch)
         grads = []
         for k, ((name, s), v) in enumerate(zip(diff_weights.slots, diff_weights.values)):
-            if s == tree.FVAL_SLOT:
+            if s in (tree.FVAL_SLOT, tree.FVAL2D_SLOT):
                 raise NotImplementedError("free-form distribution functions are not fitted through finite differences")
             g = np.zeros_like(v)
             for idx in np.ndindex(v.shape):
@@ -135,6 +156,42 @@ class LossFunction:
                     vals.append(self._angular_value(tree.combine(static_weights, tree.DiffParams(diff_weights.slots, pert)), batch)[0])
                 g[idx] = (vals[0] - vals[1]) / (2 * self.fd_step)
             grads.append(g)
+        return value, E, ts_params, tree.DiffParams(diff_weights.slots, grads)
+
+    def _vg_angular_adjoint(self, ts_params: ThomsonParams, diff_weights, batch):
+        from . import distribution as Dist
+
+        value, E, Ebar = self._angular_value(ts_params, batch, want_bar=True)
+        eng = self.ts_diag.engine(ts_params.activate)
+        ctx = self.ts_diag._angular_ctx
+        phys, P = ctx["phys"], ctx["P"]
+        p = phys[0]
+        gen = self.cfg["parameters"]["general"]
+        Pbar, (a1b, a2b) = eng.ats_adjoint(P[0], ctx["e_amps"], p[L.P_LAM], p[L.P_AMP1], p[L.P_AMP2], Ebar)
+        sm = ts_params.slots
+        want_table = any(s in (tree.GEN2D_SLOT, tree.FVAL2D_SLOT) for _, s in diff_weights.slots)
+        gp, gfe = eng.form_factor_2d_grad(0, phys, ctx["fe2"], Pbar.reshape(P.shape), gen["ud"]["angle"], gen["Va"]["angle"],
+                                          want_table=want_table)
+        gphys = gp.cpu().numpy()[0]
+        gphys[L.P_AMP1] += a1b
+        gphys[L.P_AMP2] += a2b
+        for i in range(1, sm.n_ion):  # tied ion temperatures (ts_params.py: Ti "same")
+            if sm.ti_same[i]:
+                gphys[L.P_ION0 + L.ION_TI] += gphys[L.P_ION0 + 4 * i + L.ION_TI]
+                gphys[L.P_ION0 + 4 * i + L.ION_TI] = 0.0
+        # physical -> normalised leaves: phys = act(x) * scale + shift
+        x = ts_params.X[0]
+        sg = 1.0 / (1.0 + np.exp(-x))
+        gnorm = gphys * sm.scale * np.where(sm.sigmoid.astype(bool), sg * (1.0 - sg), 1.0)
+        gfe_h = gfe.cpu().numpy() if gfe is not None else None
+        grads = []
+        for (name, s), v in zip(diff_weights.slots, diff_weights.values):
+            if s == tree.GEN2D_SLOT:
+                grads.append(ts_params.sph.vjp(gfe_h).reshape(v.shape))
+            elif s == tree.FVAL2D_SLOT:
+                grads.append(Dist.arbitrary_2v_vjp(ts_params.fval2d, ts_params.learn_log, gfe_h).reshape(v.shape))
+            else:
+                grads.append(np.full_like(v, gnorm[s]))
         return value, E, ts_params, tree.DiffParams(diff_weights.slots, grads)
 
     # ---- reference API --------------------------------------------------------------------------

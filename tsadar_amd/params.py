@@ -74,6 +74,8 @@ class SlotMap:
         self.fval_active = self.has_fval and bool(fe.get("active", False))
         # 2-D generator with a few trainable scalars (SphericalHarmonics): one leaf [1, n] at the same position
         self.gen2d_active = "sph" in self.fe_type and int(fe.get("dim", 1)) == 2 and bool(fe.get("active", False))
+        # free-form 2-D distribution (Arbitrary2V.fval, base.py:457-465): one [nvx, nvx] leaf at the same position
+        self.fval2d_active = self.fe_type == "arbitrary" and int(fe.get("dim", 1)) == 2 and bool(fe.get("active", False))
         self.n_electron_leaves = len(self.leaves)
         for i, sp in enumerate(self.species):
             ic = param_cfg[sp]
@@ -181,6 +183,8 @@ class ThomsonParams:
             other.fval = self.fval.copy()
         if getattr(self, "sph", None) is not None:
             other.sph = copy.deepcopy(self.sph)
+        if getattr(self, "fval2d", None) is not None:
+            other.fval2d = self.fval2d.copy()
         return other
 
     # ---- scipy-facing: the reference's ravel_pytree(diff_params) ordering -----------------------

@@ -15,6 +15,7 @@ from .params import ThomsonParams
 
 FVAL_SLOT = -1  # pseudo-slot of the free-form distribution-function leaf (Arbitrary1V.fval, [B, nvx])
 GEN2D_SLOT = -2  # pseudo-slot of the trainable scalars of a 2-D generator (SphericalHarmonics), [1, n]
+FVAL2D_SLOT = -3  # pseudo-slot of the free-form 2-D distribution-function leaf (Arbitrary2V.fval, [nvx, nvx])
 
 
 class DiffParams:
@@ -57,6 +58,8 @@ def get_filter_spec(cfg_params, ts_params: ThomsonParams):
             spec.append((("electron", "fval"), FVAL_SLOT))
         if k == sm.n_electron_leaves and sm.gen2d_active:
             spec.append((("electron", "fe"), GEN2D_SLOT))
+        if k == sm.n_electron_leaves and getattr(sm, "fval2d_active", False):
+            spec.append((("electron", "fval"), FVAL2D_SLOT))
         if sm.active[s]:
             spec.append((name, s))
     return spec
@@ -65,7 +68,7 @@ def get_filter_spec(cfg_params, ts_params: ThomsonParams):
 def partition(ts_params: ThomsonParams, filter_spec=None) -> Tuple[DiffParams, StaticParams]:
     spec = filter_spec if filter_spec is not None else get_filter_spec(None, ts_params)
     vals = [ts_params.fval.copy() if s == FVAL_SLOT else ts_params.sph.get_params()[None, :] if s == GEN2D_SLOT
-            else ts_params.X[:, s].copy() for _, s in spec]
+            else ts_params.fval2d.copy() if s == FVAL2D_SLOT else ts_params.X[:, s].copy() for _, s in spec]
     return DiffParams(list(spec), vals), StaticParams(ts_params)
 
 
@@ -77,6 +80,8 @@ def combine(a, b) -> ThomsonParams:
             out.fval = np.array(v, dtype=np.float64)
         elif s == GEN2D_SLOT:
             out.sph.set_params(v)
+        elif s == FVAL2D_SLOT:
+            out.fval2d = np.array(v, dtype=np.float64).reshape(out.fval2d.shape)
         else:
             out.X[:, s] = v
     return out
