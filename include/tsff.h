@@ -188,10 +188,12 @@ int tsff_form_factor_2d_range(tsff_handle *h, int32_t feature, const double *phy
  *     amplitudes and A carry none here), and, when grad_fe2d != NULL,
  *   grad_fe2d [nv][nv] (device): d loss / d fe2d[i][j] -- the table adjoint of the rotate-and-project step (bicubic
  *     weights scattered by LDS atomics, ghost cells folded back).
+ * [point_begin, point_end) (point_end < 0: to the end): the contributions of that slice of the flat point list only --
+ * both adjoints are sums over points, so the ranks of a node each take a slice and all-reduce the two outputs.
  * Replaces what JAX reverse mode gives the reference for angular fits (inverse/loops.py:167-275). */
 int tsff_form_factor_2d_grad(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
-                             double ud_angle_deg, double va_angle_deg, int32_t B, const double *Pbar,
-                             double *grad_phys, double *grad_fe2d);
+                             double ud_angle_deg, double va_angle_deg, int32_t B, int64_t point_begin,
+                             int64_t point_end, const double *Pbar, double *grad_phys, double *grad_fe2d);
 
 /* Angular (ARTS) instrument chain for one image P[G][npts][n_angles] (device; from tsff_form_factor_2d or, for a 1-D
  * distribution function, tsff_form_factor): FitModel.electron_spectrum "angular_full" branch

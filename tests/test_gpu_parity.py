@@ -839,6 +839,13 @@ def _dist_rank_2d(rank, world, port, out):
     ref = eng.form_factor_2d(0, tp.physical_matrix(), fe2, 25.0, -40.0)
     assert P.shape == ref.shape == (1, 1, 1024, 3)
     np.save(os.path.join(out, f"p{rank}.npy"), np.stack([P.cpu().numpy(), ref.cpu().numpy()]))
+    # the adjoint over the same split: each rank reverses its slice, one all-reduce of [grad_phys | grad_fe2d]
+    import torch
+
+    Pbar = torch.as_tensor(np.random.default_rng(12).standard_normal(tuple(ref.shape)), device=ref.device) / ref.abs().mean()
+    gp, gf = D.form_factor_2d_grad_sharded(eng, 0, tp.physical_matrix(), fe2, Pbar, 25.0, -40.0, world, rank)
+    gp1, gf1 = eng.form_factor_2d_grad(0, tp.physical_matrix(), fe2, Pbar, 25.0, -40.0)
+    np.savez(os.path.join(out, f"g{rank}.npz"), gp=gp.cpu().numpy(), gf=gf.cpu().numpy(), gp1=gp1.cpu().numpy(), gf1=gf1.cpu().numpy())
     dist.destroy_process_group()
 
 
@@ -862,6 +869,10 @@ def test_two_rank_sharded_form_factor_2d(torch_mod, tmp_path):
     np.testing.assert_array_equal(p0[0], p0[1])
     np.testing.assert_array_equal(p1[0], p1[1])
     np.testing.assert_array_equal(p0[0], p1[0])
+    g0, g1 = np.load(tmp_path / "g0.npz"), np.load(tmp_path / "g1.npz")
+    for k in ("gp", "gf"):   # sums in a different order: equal to rounding, identical on both ranks
+        np.testing.assert_array_equal(g0[k], g1[k])
+        assert np.max(np.abs(g0[k] - g0[k + "1"])) < 1e-11 * np.max(np.abs(g0[k + "1"])), k
 
 
 def _random_deck(seed):

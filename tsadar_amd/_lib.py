@@ -111,7 +111,7 @@ _SIGNATURES = {
     "tsff_form_factor_2d": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, _vp]),
     "tsff_form_factor_2d_range": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32,
                                             C.c_int64, C.c_int64, _vp]),
-    "tsff_form_factor_2d_grad": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, _vp, _vp, _vp]),
+    "tsff_form_factor_2d_grad": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "tsff_ats_setup": (C.c_int, [_vp, C.POINTER(TsffAtsConfig)]),
     "tsff_ats_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "tsff_ats_adjoint": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, c_double_p]),

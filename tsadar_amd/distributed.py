@@ -121,3 +121,23 @@ def form_factor_2d_sharded(engine, feature, phys, fe2d, ud_angle, va_angle, worl
     mine = full[rank * chunk : (rank + 1) * chunk].clone()
     dist.all_gather_into_tensor(full, mine, group=group)
     return full[:n].view(shape)
+
+
+def form_factor_2d_grad_sharded(engine, feature, phys, fe2d, Pbar, ud_angle, va_angle, world: int, rank: int, group=None,
+                                want_table=True):
+    """Adjoint of the 2-D path over the ranks of a node: every rank holds Pbar, the table and the parameters, reverses its
+    slice of the point list (tsff_form_factor_2d_grad with a point range) and ONE all-reduce sums the packed
+    [grad_phys | grad_fe2d] -- both are sums over points.  -> (grad_phys [B, NP], grad_fe2d [nv, nv] or None)."""
+    import torch
+
+    if world == 1:
+        return engine.form_factor_2d_grad(feature, phys, fe2d, Pbar, ud_angle, va_angle, want_table=want_table)
+    import torch.distributed as dist
+
+    n = int(Pbar.numel()) if hasattr(Pbar, "numel") else int(np.asarray(Pbar).size)
+    lo, hi, _ = point_range(n, world, rank)
+    gp, gf = engine.form_factor_2d_grad(feature, phys, fe2d, Pbar, ud_angle, va_angle, want_table=want_table, point_range=(lo, hi))
+    packed = torch.cat([gp.reshape(-1), gf.reshape(-1)]) if gf is not None else gp.reshape(-1).clone()
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    gp_out = packed[: gp.numel()].view_as(gp)
+    return gp_out, (packed[gp.numel():].view_as(gf) if gf is not None else None)

@@ -357,9 +357,10 @@ class Engine:
         L.check(self.lib, self.h, rc)
         return P
 
-    def form_factor_2d_grad(self, feature, phys, fe2d, Pbar, ud_angle=0.0, va_angle=0.0, want_table=True):
+    def form_factor_2d_grad(self, feature, phys, fe2d, Pbar, ud_angle=0.0, va_angle=0.0, want_table=True, point_range=None):
         """Adjoint of form_factor_2d (one shared table): Pbar [B, G, npts, n_angles] ->
-        (grad_phys [B, NP], grad_fe2d [nv, nv] or None) as device tensors."""
+        (grad_phys [B, NP], grad_fe2d [nv, nv] or None) as device tensors.  ``point_range = (begin, end)``: the
+        contributions of that slice of the flat point list only (to be summed over the ranks of a node)."""
         torch = self.torch
         phys_d = self.dev(phys).reshape(-1, self.NP)
         B = phys_d.shape[0]
@@ -369,8 +370,9 @@ class Engine:
         gp = torch.empty((B, self.NP), dtype=torch.float64, device=self.device)
         gf = torch.empty((nv, nv), dtype=torch.float64, device=self.device) if want_table else None
         self._sync_stream()
+        lo, hi = point_range if point_range is not None else (0, -1)
         rc = self.lib.tsff_form_factor_2d_grad(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, float(ud_angle),
-                                               float(va_angle), B, self._ptr(Pb), self._ptr(gp), self._ptr(gf))
+                                               float(va_angle), B, int(lo), int(hi), self._ptr(Pb), self._ptr(gp), self._ptr(gf))
         L.check(self.lib, self.h, rc)
         return gp, gf
 
