@@ -167,6 +167,15 @@ int tsff_chi_table(tsff_handle *h, const double *fe, int32_t n, double *W);
 int tsff_form_factor(tsff_handle *h, int32_t feature, const double *phys, const double *fe,
                      int32_t B, double *P);
 
+/* Adjoint of tsff_form_factor for an arbitrary seed Pbar = d loss / d P (device, [B][G][npts][n_angles]):
+ *   grad_phys [B][NP] (device): d loss / d PHYSICAL parameters (the DLM order m carries none here: it acts through fe),
+ *   grad_fe   [B][nvx] (device, or NULL): d loss / d fe[b][i] through both uses of the distribution function (Hermite
+ *     ln f_e lookup and the ratintn table W), fe_mode PER_LINEOUT only.
+ * The angular (ARTS) instrument chain hands back one adjoint per (wavelength, angle) point (tsff_ats_adjoint); this is
+ * what reverse-mode JAX does for angular decks with a 1-D distribution function (inverse/loops.py:167-275). */
+int tsff_form_factor_grad(tsff_handle *h, int32_t feature, const double *phys, const double *fe, int32_t B,
+                          const double *Pbar, double *grad_phys, double *grad_fe);
+
 /* FormFactor.calc_in_2D (core/physics/form_factor.py:449-587, with rotate :300-324 and calc_chi_vals :349-388)
  * for a 2-D electron distribution fe2d[nv][nv] on the grid linspace(-6 + dv/2, 6 - dv/2, nv) (first index = v_x;
  * one table shared by all lineouts when shared_fe != 0, else [B][nv][nv]): P[B][G][npts][n_angles].  `phys` holds

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "tsff_get_axes": (C.c_int, [_vp, c_double_p, c_double_p]),
     "tsff_chi_table": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
     "tsff_form_factor": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp]),
+    "tsff_form_factor_grad": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
     "tsff_form_factor_2d": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, _vp]),
     "tsff_form_factor_2d_range": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32,
                                             C.c_int64, C.c_int64, _vp]),

@@ -41,14 +41,24 @@ constexpr int kNXi1 = TSFF_NXI1;
 // ------------------------------------------------------------------------------------------
 // fast float64 reciprocal / square root for operands in the normal range (no denormal or
 // overflow rescaling, which the library forms spend ~40 % of their instructions on): the hardware
-// seed (v_rcp_f64 / v_rsq_f64) plus two Newton / Goldschmidt steps, ~1 ulp.
+// seed (v_rcp_f64 / v_rsq_f64) plus Newton / Goldschmidt refinement.  Measured on gfx950 over 4M log-uniform
+// arguments in [1e-30, 1e30] (scripts/seed_precision.hip): the seeds are good to 2^-24.4 / 2^-24.2; ONE step gives
+// 2.2e-15 (1/x), 4.1e-15 (1/sqrt) and a correctly rounded sqrt (with the final residual correction); a second step
+// reaches the last bit and costs 2 (3) more dependent FMAs on the critical path of every point.  The path's parity
+// budget is 1e-9 (north_star: 1e-5), so one step is what is used.
 // ------------------------------------------------------------------------------------------
+#ifndef TSFF_NEWTON
+#define TSFF_NEWTON 1  // refinement steps after the hardware seed (see the table above)
+#endif
 __device__ __forceinline__ double frcp(double x) {
   double y = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, y, 1.0);
   y = __builtin_fma(y, e, y);
+#if TSFF_NEWTON > 1
   e = __builtin_fma(-x, y, 1.0);
-  return __builtin_fma(y, e, y);
+  y = __builtin_fma(y, e, y);
+#endif
+  return y;
 }
 
 // s = sqrt(x), is = 1/sqrt(x)
@@ -58,9 +68,11 @@ __device__ __forceinline__ void fsqrt2(double x, double& s, double& is) {
   double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g);
   h = __builtin_fma(h, r, h);
+#if TSFF_NEWTON > 1
   r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g);
   h = __builtin_fma(h, r, h);
+#endif
   const double d = __builtin_fma(-g, g, x);
   s = __builtin_fma(d, h, g);
   is = h + h;
@@ -375,8 +387,8 @@ __device__ __forceinline__ void make_lines_adjoint(const Phys<NI>& p, double lam
 // ------------------------------------------------------------------------------------------
 
 // exp(x) for x <= ~1 (arguments here are ln f_e in [-50, 2] and -xi_i^2 <= 0): Cody-Waite reduction by
-// ln 2 and a degree-13 Taylor polynomial on |r| <= ln2/2 (truncation 4e-18); no overflow handling,
-// underflow to 0 through v_ldexp_f64.  ~1 ulp, 19 instructions instead of the library's ~30.
+// ln 2 and a Taylor polynomial on |r| <= ln2/2; no overflow handling, underflow to 0 through v_ldexp_f64.
+// TSFF_FEXP: 1 degree 13 Horner (truncation 4e-18, ~1 ulp), 2 degree 11 Horner (6.4e-15), 3 degree 11 Estrin.
 #ifndef TSFF_FEXP
 #define TSFF_FEXP 1
 #endif
@@ -391,6 +403,7 @@ __device__ __forceinline__ double fexp(double x) {
   const double n = __builtin_rint(x * 1.4426950408889634074);
   double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
   r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+#if TSFF_FEXP == 1
   double p = 1.6059043836821613e-10;                 // 1/13!
   p = __builtin_fma(p, r, 2.08767569878681e-09);     // 1/12!
   p = __builtin_fma(p, r, 2.505210838544172e-08);    // 1/11!
@@ -405,6 +418,36 @@ __device__ __forceinline__ double fexp(double x) {
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
+#elif TSFF_FEXP == 2
+  double p = 2.505210838544172e-08;                  // 1/11!  (truncation |r|^12 / 12! <= 6.4e-15 on |r| <= ln2/2)
+  p = __builtin_fma(p, r, 2.755731922398589e-07);    // 1/10!
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);   // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873e-05);     // 1/8!
+  p = __builtin_fma(p, r, 1.984126984126984e-04);    // 1/7!
+  p = __builtin_fma(p, r, 1.388888888888889e-03);    // 1/6!
+  p = __builtin_fma(p, r, 8.333333333333333e-03);    // 1/5!
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);   // 1/4!
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);   // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+#else
+  // degree 11, Estrin's scheme: 11 FMAs + 3 multiplies in a dependency chain of depth 4 instead of 12
+  const double r2 = r * r;
+  const double a0 = __builtin_fma(r, 1.0, 1.0);
+  const double a1 = __builtin_fma(r, 1.6666666666666666e-01, 0.5);
+  const double a2 = __builtin_fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);
+  const double a3 = __builtin_fma(r, 1.984126984126984e-04, 1.388888888888889e-03);
+  const double a4 = __builtin_fma(r, 2.7557319223985893e-06, 2.48015873015873e-05);
+  const double a5 = __builtin_fma(r, 2.505210838544172e-08, 2.755731922398589e-07);
+  const double r4 = r2 * r2;
+  const double b0 = __builtin_fma(a1, r2, a0);
+  const double b1 = __builtin_fma(a3, r2, a2);
+  const double b2 = __builtin_fma(a5, r2, a4);
+  const double r8 = r4 * r4;
+  const double d0 = __builtin_fma(b1, r4, b0);
+  const double p = __builtin_fma(b2, r8, d0);
+#endif
   return ldexp(p, (int)n);
 }
 

@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, in
       double ksv[kStrip + 1];
 #pragma unroll
       for (int q = 0; q <= kStrip; ++q) ksv[q] = ks_eval(ws[q], L.wpe2);
-      for (int a = 0; a < NA; ++a) {
+      for (int a = blockIdx.y; a < NA; a += gridDim.y) {   // (few lineouts, many angles: the angles are spread over blockIdx.y)
         const double ct = m.cosa[a];
         Base b0;
         base_eval<NI>(ws[0], ksv[0], ct, L, T, b0);
@@ -1243,6 +1243,99 @@ __global__ __launch_bounds__(kThreads) void k_form_factor(KStatic S, KCall K, in
           b0 = b1;
         }
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_form_factor_adj: reverse of k_form_factor for an arbitrary seed Pbar[b][g][j][a] (the angular instrument chain hands
+// one back per (wavelength, angle) point, unlike the fit path whose seed is a spectrum adjoint times the angle
+// weights).  The reverse sweep of k_spectrum with the same device functions: every point is recomputed and reversed,
+// the lineout-scalar adjoints are reduced per workgroup and added to LBacc[b][g][:] (k_ff_lines_adj finishes the chain to
+// the physical parameters), and with GM == 2 the adjoints of the two distribution-function tables are gathered in LDS
+// and added to Wb_out / Hy_out / Hs_out (k_wgemm_t and k_fe_adjoint chain them to f_e, as for tsff_loss_grad_fe).
+// Grid (B, angle chunks).
+// ------------------------------------------------------------------------------------------
+template <int NI, int GM>
+__global__ __launch_bounds__(kThreads) void k_form_factor_adj(KStatic S, KCall K, int f, const double* __restrict__ omgs,
+                                                              int npts, const double* __restrict__ Pbar,
+                                                              double* __restrict__ LBacc) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const Smem m = carve(smem, S, 1, GM != 0, false);
+  Tables T;
+  load_tables(m, S, K, S.shared_fe ? 0 : b, false, T);
+  Phys<NI> p;
+  load_phys<NI>(K.params + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, false, p);
+  if (GM == 2) {
+    T.Wb = m.Wm; T.Hy = reinterpret_cast<double*>(m.hcm); T.Hs = T.Hy + S.nvx;
+    for (int i = tid; i < kNXi2; i += kThreads) T.Wb[i] = 0.0;
+    for (int i = tid; i < 2 * S.nvx; i += kThreads) T.Hy[i] = 0.0;
+  }
+  __syncthreads();
+  constexpr int NLB = 9 + 3 * NI;
+  const int G = S.G, NA = S.n_angles;
+  const int nstrips = (npts + kStrip - 1) / kStrip;
+  FeAcc fa;
+  fe_acc_init(fa);
+  for (int g = 0; g < G; ++g) {
+    LineS<NI> L, LB;
+    make_lines<NI>(p, S.lam_shift[f], g, G, L);
+    zero_lines<NI>(LB);
+    for (int st = tid; st < nstrips; st += kThreads) {
+      const int j0 = st * kStrip;
+      double ws[kStrip + 1], ksv[kStrip + 1];
+#pragma unroll
+      for (int q = 0; q <= kStrip; ++q) { ws[q] = omgs[min(j0 + q, npts - 1)]; ksv[q] = ks_eval(ws[q], L.wpe2); }
+      for (int a = blockIdx.y; a < NA; a += gridDim.y) {
+        const double ct = m.cosa[a];
+        Base b0;
+        base_eval<NI>(ws[0], ksv[0], ct, L, T, b0);
+        double cxe = 0.0, cF = 0.0;
+#pragma unroll
+        for (int q = 0; q < kStrip; ++q) {
+          const int j = j0 + q;
+          const bool has_next = (j + 1) < npts;
+          Base b1;
+          base_eval<NI>(ws[q + 1], ksv[q + 1], ct, L, T, b1);
+          if (j < npts) {
+            BaseAdj ba;
+            double xen, Fn;
+            point_reverse<NI, GM>(ws[q], b0, b1, has_next, L, T, Pbar[(((size_t)b * G + g) * npts + j) * NA + a], ba, xen, Fn,
+                                  LB, fa);
+            ba.xe += cxe; ba.F += cF;
+            base_reverse<NI, GM>(ct, b0, L, T, ba, LB, fa);
+            cxe = xen; cF = Fn;
+          }
+          b0 = b1;
+        }
+        if (j0 + kStrip < npts) {  // the strip's right neighbour receives the D-coupling of the last point
+          BaseAdj ba;
+          ba.k2 = ba.ik = ba.wd = 0.0; ba.xe = cxe; ba.F = cF;
+          base_reverse<NI, GM>(ct, b0, L, T, ba, LB, fa);
+        }
+      }
+    }
+    double lb[NLB];
+    lb[0] = LB.wpe2; lb[1] = LB.wL; lb[2] = LB.kL; lb[3] = LB.ivTe; lb[4] = LB.a_e; lb[5] = LB.pref; lb[6] = LB.Ud; lb[7] = LB.Vd;
+#pragma unroll
+    for (int s = 0; s < NI; ++s) { lb[8 + 3 * s] = LB.ixi[s]; lb[9 + 3 * s] = LB.a_i[s]; lb[10 + 3 * s] = LB.cs[s]; }
+    lb[NLB - 1] = LB.m;
+#pragma unroll
+    for (int k = 0; k < NLB; ++k) {
+      const double v = wave_sum(lb[k]);
+      if (lane == 0) atomicAdd(LBacc + ((size_t)b * G + g) * NLB + k, v);
+    }
+  }
+  if (GM == 2) {
+    fe_flush_w(fa, T.Wb);
+    fe_flush_h(fa, T.Hy, T.Hs);
+    __syncthreads();
+    for (int i = tid; i < kNXi2; i += kThreads)
+      if (T.Wb[i] != 0.0) atomicAdd(K.Wb_out + (size_t)b * kNXi2 + i, T.Wb[i]);
+    for (int i = tid; i < S.nvx; i += kThreads) {
+      if (T.Hy[i] != 0.0) atomicAdd(K.Hy_out + (size_t)b * S.nvx + i, T.Hy[i]);
+      if (T.Hs[i] != 0.0) atomicAdd(K.Hs_out + (size_t)b * S.nvx + i, T.Hs[i]);
     }
   }
 }
@@ -1973,10 +2066,11 @@ __global__ __launch_bounds__(kThreads) void k_ff2d_fold_ghosts(int nv, double* _
 // LBacc[b][g][NLB] -> gphys[b][NP]: make_lines_adjoint per gradient point, summed (one thread per lineout)
 template <int NI>
 __global__ void k_ff2d_lines_adj(KStatic S, const double* __restrict__ phys, int f, int B, const double* __restrict__ LBacc,
-                                 double* __restrict__ gphys) {
+                                 double* __restrict__ gphys, int with_m) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  constexpr int NPk = TSFF_NP(NI), NLB = kNLB2 + 3 * NI;
+  constexpr int NPk = TSFF_NP(NI);
+  const int NLB = kNLB2 + 3 * NI + (with_m ? 1 : 0);   // (the 1-D path carries one more slot: the DLM-order tangent)
   Phys<NI> p;
   load_phys<NI>(phys + (size_t)b * S.NP, S.p_scale, S.p_shift, S.p_sig, S.ti_same, false, p);
   double pb[NPk];
@@ -1990,6 +2084,7 @@ __global__ void k_ff2d_lines_adj(KStatic S, const double* __restrict__ phys, int
     LB.wpe2 = o[0]; LB.wL = o[1]; LB.kL = o[2]; LB.ivTe = o[3]; LB.a_e = o[4]; LB.pref = o[5]; LB.Ud = o[6]; LB.Vd = o[7];
 #pragma unroll
     for (int s = 0; s < NI; ++s) { LB.ixi[s] = o[8 + 3 * s]; LB.a_i[s] = o[9 + 3 * s]; LB.cs[s] = o[10 + 3 * s]; }
+    if (with_m) LB.m = o[NLB - 1];
     make_lines_adjoint<NI>(p, S.lam_shift[f], g, S.G, L, LB, pb);
   }
 #pragma unroll

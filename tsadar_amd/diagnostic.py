@@ -72,13 +72,14 @@ class ThomsonScatteringDiagnostic:
                           min(cfg["data"]["lineouts"]["end"], n_px // ang_step), self.irf_cutoff_sigmas)
             eng._ats_key = key
         phys = ts_params.physical_matrix()
-        fe2 = None
+        fe2 = fe1 = None
         if eng.fe_dim == 2:
             gen = cfg["parameters"]["general"]
             fe2 = eng.dev(np.ascontiguousarray(ts_params()["electron"]["fe"], dtype=np.float64))
             P = eng.form_factor_2d(0, phys, fe2, gen["ud"]["angle"], gen["Va"]["angle"])
         else:
-            P = eng.form_factor(0, phys, np.asarray(ts_params()["electron"]["fe"]).reshape(1, -1))
+            fe1 = np.ascontiguousarray(np.asarray(ts_params()["electron"]["fe"], dtype=np.float64).reshape(1, -1))
+            P = eng.form_factor(0, phys, fe1)
         p = phys[0]
         rows = eng._ats_shape[0]
         e_amps = np.broadcast_to(np.asarray(batch["e_amps"], dtype=np.float64).reshape(-1, 1), (rows, 1))
@@ -86,7 +87,7 @@ class ThomsonScatteringDiagnostic:
         E = E + np.asarray(batch["noise_e"])
         lamE = np.mean(wavelength_axis_nm(cfg["other"]["lamrangE"], eng.npts).reshape(-1, lam_step), axis=1)
         # what the adjoint (LossFunction._vg_angular) needs again: the device-resident P, the table and the parameters
-        self._angular_ctx = dict(P=P, phys=phys, fe2=fe2, e_amps=e_amps)
+        self._angular_ctx = dict(P=P, phys=phys, fe2=fe2, fe1=fe1, e_amps=e_amps)
         return E, 0 + np.asarray(batch["noise_i"]), lamE, []
 
     def spectrum_breakdown(self, ts_params, batch):

@@ -334,6 +334,19 @@ class Engine:
         L.check(self.lib, self.h, self.lib.tsff_form_factor(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), B, self._ptr(P)))
         return P
 
+    def form_factor_grad(self, feature, phys, fe, Pbar, want_fe=False):
+        """Adjoint of form_factor: Pbar [B, G, npts, n_angles] -> (grad_phys [B, NP], grad_fe [B, nvx] or None)."""
+        torch = self.torch
+        phys_d = self.dev(phys).reshape(-1, self.NP)
+        B = phys_d.shape[0]
+        fe_d, Pb = self.dev(fe), self.dev(Pbar)
+        gp = torch.empty((B, self.NP), dtype=torch.float64, device=self.device)
+        gf = torch.empty((B, int(self._cfg_struct.nvx)), dtype=torch.float64, device=self.device) if want_fe else None
+        self._sync_stream()
+        L.check(self.lib, self.h, self.lib.tsff_form_factor_grad(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), B,
+                                                                 self._ptr(Pb), self._ptr(gp), self._ptr(gf)))
+        return gp, gf
+
     def form_factor_2d(self, feature, phys, fe2d, ud_angle=0.0, va_angle=0.0, point_range=None, out=None):
         """FormFactor.calc_in_2D: phys [B, NP] PHYSICAL parameters, fe2d [nv, nv] (shared) or [B, nv, nv]
         -> P [B, G, npts, n_angles].  ``point_range = (begin, end)`` evaluates that slice of the flat point list only

@@ -133,14 +133,14 @@ class LossFunction:
         return e_error, E, derr * wcol[None, :]
 
     def _vg_angular(self, diff_weights, static_weights, batch):
-        """Value and gradient of the angular model.  2-D distribution functions (the expensive case: one rotated
-        projection of the table per (wavelength, angle) point) go through the hand-written adjoint -- loss seed ->
-        tsff_ats_adjoint -> tsff_form_factor_2d_grad -> chain rule of the parameter transform and of the table
-        generator -- at the cost of about three forward evaluations whatever the number of parameters, which is what
-        reverse-mode JAX gives the reference (loops.py:167-275).  1-D distribution functions (1 ms forwards) keep the
-        central difference over the trainable scalar leaves, step ``fd_step`` in normalised units."""
+        """Value and gradient of the angular model by the hand-written adjoint -- loss seed -> tsff_ats_adjoint ->
+        tsff_form_factor_2d_grad (2-D distribution functions: one rotated projection of the table per (wavelength, angle)
+        point) or tsff_form_factor_grad (1-D) -> chain rule of the parameter transform and of the distribution-function
+        generator -- at the cost of a few forward evaluations whatever the number of parameters, which is what
+        reverse-mode JAX gives the reference (loops.py:167-275).  ``force_fd`` switches to central differences over
+        the trainable scalar leaves (step ``fd_step`` in normalised units), kept as a cross-check."""
         ts_params = tree.combine(static_weights, diff_weights)
-        if ts_params.fe_dim == 2 and not getattr(self, "force_fd", False):
+        if not getattr(self, "force_fd", False):
             return self._vg_angular_adjoint(ts_params, diff_weights, batch)
         value, E = self._angular_value(ts_params, batch)
         grads = []
@@ -169,10 +169,21 @@ class LossFunction:
         gen = self.cfg["parameters"]["general"]
         Pbar, (a1b, a2b) = eng.ats_adjoint(P[0], ctx["e_amps"], p[L.P_LAM], p[L.P_AMP1], p[L.P_AMP2], Ebar)
         sm = ts_params.slots
-        want_table = any(s in (tree.GEN2D_SLOT, tree.FVAL2D_SLOT) for _, s in diff_weights.slots)
-        gp, gfe = eng.form_factor_2d_grad(0, phys, ctx["fe2"], Pbar.reshape(P.shape), gen["ud"]["angle"], gen["Va"]["angle"],
-                                          want_table=want_table)
+        gfe_h = None
+        if ts_params.fe_dim == 2:
+            want_table = any(s in (tree.GEN2D_SLOT, tree.FVAL2D_SLOT) for _, s in diff_weights.slots)
+            gp, gfe = eng.form_factor_2d_grad(0, phys, ctx["fe2"], Pbar.reshape(P.shape), gen["ud"]["angle"], gen["Va"]["angle"],
+                                              want_table=want_table)
+        else:
+            want_fe = any(s in (tree.FVAL_SLOT, L.P_M) for _, s in diff_weights.slots)
+            gp, gfe = eng.form_factor_grad(0, phys, ctx["fe1"], Pbar.reshape(P.shape), want_fe=want_fe)
         gphys = gp.cpu().numpy()[0]
+        gfe_h = gfe.cpu().numpy() if gfe is not None else None
+        if ts_params.fe_dim == 1 and sm.has_m and gfe_h is not None:
+            # DLM order: f_e = dlm(m) is a cheap host generator; its derivative by central differences, contracted
+            # with d loss / d f_e from the GPU
+            nvx, mval, hm = ctx["fe1"].shape[1], float(phys[0, L.P_M]), 1e-6
+            gphys[L.P_M] = float(np.dot(gfe_h[0], (Dist.dlm(mval + hm, nvx) - Dist.dlm(mval - hm, nvx)) / (2 * hm)))
         gphys[L.P_AMP1] += a1b
         gphys[L.P_AMP2] += a2b
         for i in range(1, sm.n_ion):  # tied ion temperatures (ts_params.py: Ti "same")
@@ -183,10 +194,11 @@ class LossFunction:
         x = ts_params.X[0]
         sg = 1.0 / (1.0 + np.exp(-x))
         gnorm = gphys * sm.scale * np.where(sm.sigmoid.astype(bool), sg * (1.0 - sg), 1.0)
-        gfe_h = gfe.cpu().numpy() if gfe is not None else None
         grads = []
         for (name, s), v in zip(diff_weights.slots, diff_weights.values):
-            if s == tree.GEN2D_SLOT:
+            if s == tree.FVAL_SLOT:
+                grads.append(Dist.arbitrary_1v_vjp(ts_params.fval, gfe_h).reshape(v.shape))
+            elif s == tree.GEN2D_SLOT:
                 grads.append(ts_params.sph.vjp(gfe_h).reshape(v.shape))
             elif s == tree.FVAL2D_SLOT:
                 grads.append(Dist.arbitrary_2v_vjp(ts_params.fval2d, ts_params.learn_log, gfe_h).reshape(v.shape))
