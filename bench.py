@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="lineouts per GPU")
     ap.add_argument("--ppp", type=int, default=1, help="points per pixel (1 -> 1024 wavelength points per feature)")
+    ap.add_argument("--nvx", type=int, default=128, help="velocity grid of f_e (BASELINE: 128; the reference's production decks: 320)")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="lineouts of the CPU baseline (0 = skip)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: forward-only (not the headline metric)")
     ap.add_argument("--dlm", action="store_true",
@@ -98,7 +99,7 @@ def main():
 
     cpu_res = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_sample > 0 and not args.forward_only and not variant:
-        cpu_res = cpu_baseline(S.baseline_deck(points_per_pixel=args.ppp, batch_size=args.batch), args.batch, args.cpu_sample)
+        cpu_res = cpu_baseline(S.baseline_deck(points_per_pixel=args.ppp, nvx=args.nvx, batch_size=args.batch), args.batch, args.cpu_sample)
 
     import torch
 
@@ -115,7 +116,7 @@ def main():
 
     B = args.batch
     active = ("Te", "ne", "m", "amp1", "amp2", "lam") if args.dlm else S.ACTIVE
-    cfg = S.baseline_deck(points_per_pixel=args.ppp, batch_size=B, active=active)
+    cfg = S.baseline_deck(points_per_pixel=args.ppp, nvx=args.nvx, batch_size=B, active=active)
     from tsadar_amd.calibration import sa_lookup
 
     sa = sa_lookup("P9")
@@ -215,7 +216,7 @@ def main():
     if cands and not args.forward_only and not variant:
         tfile = cands[-1]
         tj = json.load(open(tfile))
-        if tj.get("B") == B and tj.get("ppp") == args.ppp:
+        if tj.get("B") == B and tj.get("ppp") == args.ppp and args.nvx == 128:
             traffic = tj["hbm_bytes_per_launch"]
     abytes = algorithmic_bytes(eng.NP, with_noise=False) if not args.forward_only else (eng.NP * 8 + 16 + 2 * 1024 * 8)
     achieved = B * abytes / kavg_s / 1e9
@@ -245,6 +246,7 @@ def main():
             "global_batch": B * world,
             "n_lambda": 1024 * args.ppp,
             "n_angles": 10,
+            "nvx": args.nvx,
             "free_params": P,
             "parallelism": f"lineout-sharded x{world}, one all-reduce of [3 + B*P] f64 per step" if world > 1 else "single GPU",
         },

@@ -10,3 +10,5 @@ run --ppp 2
 run --ppp 5 --batch 1024
 run --dlm
 run --free-form
+run --nvx 320
+run --nvx 320 --dlm

@@ -194,12 +194,23 @@ def test_gradient_baseline_active_set(torch_mod):
     _grad_case(torch_mod, ("Te", "ne", "Ti", "Va", "lam", "amp1"), ["Te", "ne", "Ti_1", "Va", "lam", "amp1"], B=3, seed=9)
 
 
-def test_gradient_dlm_order(torch_mod):
+def test_gradient_production_velocity_grid(torch_mod):
+    """a15 with nvx = 320, the velocity grid of the reference's production decks (configs/1d/inputs.yaml:52): larger
+    Hermite tables in LDS, the launch planner's budget decisions change."""
+    def tweak(cfg):
+        cfg["parameters"]["electron"]["fe"]["nvx"] = 320
+
+    _grad_case(torch_mod, ("Te", "ne", "Ti", "Va", "lam", "amp1"), ["Te", "ne", "Ti_1", "Va", "lam", "amp1"], B=2, seed=19, tweak=tweak)
+
+
+@pytest.mark.parametrize("nvx", [128, 320])
+def test_gradient_dlm_order(torch_mod, nvx):
     """the reference's canonical active set {Te, ne, m, amp1, amp2, lam} -- the gradient
     w.r.t. the super-Gaussian order m flows through the ln f_e Hermite table and the W table
-    (per-lineout tables by k_fe_vectors + k_wgemm)."""
+    (per-lineout tables by k_fe_vectors + k_wgemm).  nvx = 320: the production velocity grid."""
     def tweak(cfg):
         cfg["parameters"]["electron"]["fe"]["params"]["m"]["val"] = 2.7
+        cfg["parameters"]["electron"]["fe"]["nvx"] = nvx
 
     B = 3
     names = ["Te", "ne", "m", "amp1", "amp2", "lam"]
@@ -692,7 +703,7 @@ def _free_form_fe(B, nvx, seed):
     return np.stack(fes)
 
 
-@pytest.mark.parametrize("nvx", [128, 64])
+@pytest.mark.parametrize("nvx", [128, 64, 320])
 def test_gradient_wrt_distribution_function(torch_mod, nvx):
     """SURVEY 8(f1), free-form f_e: d loss / d fe[b, i] from tsff_loss_grad_fe (table adjoints scattered in k_spectrum,
     transposed MFMA GEMM with the log-ratio table, k_fe_adjoint) vs reverse-mode autodiff of the oracle twin through
