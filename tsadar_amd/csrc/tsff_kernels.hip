@@ -1369,22 +1369,53 @@ __device__ __forceinline__ void catmull_rom(double t, double w[4]) {
 // outside the grid, extrap=True) is the same formula with the cell index clamped and t left free.  Every sample then
 // takes one straight-line path: 4 x 4 consecutive entries, no index clamps, no divergence between lanes.
 // Fp points at the ghost corner; pitch = row pitch in doubles of the padded table.
-__device__ __forceinline__ double bicubic_sample(const double* __restrict__ Fp, int nv, int pitch, double v0, double dv,
-                                                 double idv, double xq, double yq) {
-  int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
-  cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
-  cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
-  double wx[4], wy[4];
-  catmull_rom((xq - (v0 + cx * dv)) * idv, wx);
-  catmull_rom((yq - (v0 + cy * dv)) * idv, wy);
+// (u, v): the sample position in CELL units, u = (xq - vx[0]) / dv.  Along a rotated line the callers advance it as
+// u = u0 + ix cos(beta), v = v0 + ix sin(beta) -- one FMA per axis instead of rotating, shifting and scaling every sample.
+__device__ __forceinline__ void cell_of(double u, int nv, int& c, double& t) {
+  c = (int)floor(u);
+  c = c < 0 ? 0 : (c > nv - 2 ? nv - 2 : c);
+  t = u - (double)c;   // free outside the grid: the edge-cell polynomial continued (extrap=True)
+}
+__device__ __forceinline__ double bicubic_sample(const double* __restrict__ Fp, int nv, int pitch, double u, double v) {
+  int cx, cy;
+  double tx, ty, wx[4], wy[4];
+  cell_of(u, nv, cx, tx);
+  cell_of(v, nv, cy, ty);
+  catmull_rom(tx, wx);
+  catmull_rom(ty, wy);
   const double* __restrict__ q0 = Fp + (size_t)cx * pitch + cy;  // padded index of node (cx - 1, cy - 1)
-  double v = 0.0;
+  double r = 0.0;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const double* __restrict__ row = q0 + (size_t)m * pitch;
-    v += wx[m] * (wy[0] * row[0] + wy[1] * row[1] + wy[2] * row[2] + wy[3] * row[3]);
+    r += wx[m] * (wy[0] * row[0] + wy[1] * row[1] + wy[2] * row[2] + wy[3] * row[3]);
   }
-  return v;
+  return r;
+}
+// two-stage form of the sampler for tables read through L1/L2: the 16 stencil values of the NEXT sample are requested
+// before the current one is contracted, so that a wavefront keeps loads in flight while it computes (203 -> 190 ms at
+// 256^2; with the table in LDS the same change loses 8 %: there the LDS pipe, not its latency, is the limit)
+__device__ __forceinline__ void bicubic_fetch(const double* __restrict__ Fp, int pitch, int cx, int cy, double V[16]) {
+  const double* __restrict__ q0 = Fp + (size_t)cx * pitch + cy;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double* __restrict__ row = q0 + (size_t)m * pitch;
+    V[4 * m] = row[0]; V[4 * m + 1] = row[1]; V[4 * m + 2] = row[2]; V[4 * m + 3] = row[3];
+  }
+}
+__device__ __forceinline__ double bicubic_dot(const double V[16], double tx, double ty) {
+  double wx[4], wy[4];
+  catmull_rom(tx, wx);
+  catmull_rom(ty, wy);
+  double r = 0.0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) r += wx[m] * (wy[0] * V[4 * m] + wy[1] * V[4 * m + 1] + wy[2] * V[4 * m + 2] + wy[3] * V[4 * m + 3]);
+  return r;
+}
+// cell coordinates of sample (ix, iy) of the grid rotated by (cb, sb): u = ix cb + u0, v = ix sb + v0
+__device__ __forceinline__ void line_origin(double cb, double sb, double y, double vx0, double idv, double& u0, double& v0c) {
+  u0 = (vx0 * cb - y * sb - vx0) * idv;
+  v0c = (vx0 * sb + y * cb - vx0) * idv;
 }
 
 // ghost cells of a padded table P[(nv + 2)][pitch] whose interior [1..nv][1..nv] is filled: rows first, then columns
@@ -1432,7 +1463,16 @@ constexpr int kSc2 = 40;  // doubles of per-group scalar scratch
 // Row pitch of the padded (nv + 2)^2 table.  In LDS it is made odd: with an even (worse: power-of-two) pitch the rows
 // start in the same banks and the lanes of a wavefront (neighbouring points of a rotated line) collide whenever the line
 // runs along the first table axis.
-__host__ __device__ inline int pitch2d(int nv, bool lds) { return lds ? ((nv + 2) | 1) : nv + 2; }
+__host__ __device__ inline int pitch2d(int nv, bool lds) {
+  if (!lds) return nv + 2;
+  // LDS bank model: the 32 lanes of a half wavefront read one double each; doubles a != b collide when a = b (mod 32).
+  // The lanes are neighbouring samples of a rotated line, i.e. a digital straight line of cells, and with
+  // bank = (pitch cx + cy) mod 32 the passes per read depend on pitch mod 32 (simulated over all directions / measured
+  // by SQ_LDS_BANK_CONFLICT): 1 -> 1.49, 2 -> 1.78 / 1.8, 3 -> 1.97 / 1.96, growing to 2.4 at 10.  1 where the LDS
+  // budget allows it (nv <= 96), else 2.
+  const int r = nv <= 96 ? 1 : 2;
+  return nv + 2 + ((r - (nv + 2) % 32) + 32) % 32;
+}
 // per-group scratch: f1, d1 [nv], part [nparts][nv] (nparts = 4, 2, 1 for nv <= 64, 128, larger), red [8], scalars
 __host__ __device__ inline size_t group2d_doubles(int nv) {
   const int nparts = nv <= 64 ? 4 : (nv <= 128 ? 2 : 1);
@@ -1506,23 +1546,41 @@ __global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d(KStatic S, co
         if (iy < nv) {
           const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
           const double y = v0 + iy * dv;
-          double acc = 0.0;
-          for (int ix = ix0; ix < ix1; ++ix) {
-            const double x = v0 + ix * dv;
-            const double xq = x * cb - y * sb, yq = x * sb + y * cb;
-            acc += bicubic_sample(F, nv, pitch, v0, dv, idv, xq, yq);
+          double acc = 0.0, ul, vl, xi_d = (double)ix0;
+          line_origin(cb, sb, y, v0, idv, ul, vl);
+          if (LDS) {
+            for (int ix = ix0; ix < ix1; ++ix, xi_d += 1.0)
+              acc += bicubic_sample(F, nv, pitch, __builtin_fma(xi_d, cb, ul), __builtin_fma(xi_d, sb, vl));
+          } else {
+            int cx, cy;
+            double tx, ty, V[16];
+            cell_of(__builtin_fma(xi_d, cb, ul), nv, cx, tx);
+            cell_of(__builtin_fma(xi_d, sb, vl), nv, cy, ty);
+            bicubic_fetch(F, pitch, cx, cy, V);
+            for (int ix = ix0; ix < ix1; ++ix) {
+              xi_d += 1.0;   // (the fetch after the last sample repeats a valid position: no branch in the loop)
+              const double xn = ix + 1 < ix1 ? xi_d : xi_d - 1.0;
+              int ncx, ncy;
+              double ntx, nty, N[16];
+              cell_of(__builtin_fma(xn, cb, ul), nv, ncx, ntx);
+              cell_of(__builtin_fma(xn, sb, vl), nv, ncy, nty);
+              bicubic_fetch(F, pitch, ncx, ncy, N);
+              __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the arithmetic on the previous sample
+              acc += bicubic_dot(V, tx, ty);
+#pragma unroll
+              for (int k = 0; k < 16; ++k) V[k] = N[k];
+              tx = ntx; ty = nty;
+            }
           }
           part[pt * nv + iy] = acc;
         }
       } else {
         for (int iy = gt; iy < nv; iy += kThreads) {
           const double y = v0 + iy * dv;
-          double acc = 0.0;
-          for (int ix = 0; ix < nv; ++ix) {
-            const double x = v0 + ix * dv;
-            const double xq = x * cb - y * sb, yq = x * sb + y * cb;
-            acc += bicubic_sample(F, nv, pitch, v0, dv, idv, xq, yq);
-          }
+          double acc = 0.0, ul, vl, xi_d = 0.0;
+          line_origin(cb, sb, y, v0, idv, ul, vl);
+          for (int ix = 0; ix < nv; ++ix, xi_d += 1.0)
+            acc += bicubic_sample(F, nv, pitch, __builtin_fma(xi_d, cb, ul), __builtin_fma(xi_d, sb, vl));
           part[iy] = acc;
         }
       }
@@ -1609,12 +1667,12 @@ __global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d(KStatic S, co
 constexpr int kNLB2 = 8;  // + 3 per ion: wpe2, wL, kL, ivTe, a_e, pref, Ud, Vd | ixi, a_i, cs
 
 // value and both first derivatives of one bicubic sample (ghost-padded table, see bicubic_sample)
-__device__ __forceinline__ void bicubic_sample_grad(const double* __restrict__ Fp, int nv, int pitch, double v0, double dv,
-                                                    double idv, double xq, double yq, double& Sx, double& Sy) {
-  int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
-  cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
-  cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
-  const double tx = (xq - (v0 + cx * dv)) * idv, ty = (yq - (v0 + cy * dv)) * idv;
+__device__ __forceinline__ void bicubic_sample_grad(const double* __restrict__ Fp, int nv, int pitch, double idv, double u,
+                                                    double v, double& Sx, double& Sy) {
+  int cx, cy;
+  double tx, ty;
+  cell_of(u, nv, cx, tx);
+  cell_of(v, nv, cy, ty);
   double wx[4], wy[4], dx[4], dy[4];
   catmull_rom(tx, wx);
   catmull_rom(ty, wy);
@@ -1632,7 +1690,7 @@ __device__ __forceinline__ void bicubic_sample_grad(const double* __restrict__ F
     sx += dx[m] * r;
     sy += wx[m] * rd;
   }
-  Sx = sx * idv;
+  Sx = sx * idv;   // d / d xq = (1 / dv) d / du
   Sy = sy * idv;
 }
 
@@ -1708,21 +1766,19 @@ __global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d_adj(KStatic S
         if (iy < nv) {
           const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
           const double y = v0 + iy * dv;
-          double acc = 0.0;
-          for (int ix = ix0; ix < ix1; ++ix) {
-            const double x = v0 + ix * dv;
-            acc += bicubic_sample(F, nv, pitch, v0, dv, idv, x * cb - y * sb, x * sb + y * cb);
-          }
+          double acc = 0.0, ul, vl, xi_d = (double)ix0;
+          line_origin(cb, sb, y, v0, idv, ul, vl);
+          for (int ix = ix0; ix < ix1; ++ix, xi_d += 1.0)
+            acc += bicubic_sample(F, nv, pitch, __builtin_fma(xi_d, cb, ul), __builtin_fma(xi_d, sb, vl));
           part[pt * nv + iy] = acc;
         }
       } else {
         for (int iy = gt; iy < nv; iy += kThreads) {
           const double y = v0 + iy * dv;
-          double acc = 0.0;
-          for (int ix = 0; ix < nv; ++ix) {
-            const double x = v0 + ix * dv;
-            acc += bicubic_sample(F, nv, pitch, v0, dv, idv, x * cb - y * sb, x * sb + y * cb);
-          }
+          double acc = 0.0, ul, vl, xi_d = 0.0;
+          line_origin(cb, sb, y, v0, idv, ul, vl);
+          for (int ix = 0; ix < nv; ++ix, xi_d += 1.0)
+            acc += bicubic_sample(F, nv, pitch, __builtin_fma(xi_d, cb, ul), __builtin_fma(xi_d, sb, vl));
           part[iy] = acc;
         }
       }
@@ -1895,11 +1951,12 @@ __global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d_adj(KStatic S
         if (iy < nv) {
           const int ix0 = (nv * pt) / nparts, ix1 = (nv * (pt + 1)) / nparts;
           const double y = v0 + iy * dv;
-          double s1 = 0.0, s2 = 0.0;
+          double s1 = 0.0, s2 = 0.0, ul, vl;
+          line_origin(cb, sb, y, v0, idv, ul, vl);
           for (int ix = ix0; ix < ix1; ++ix) {
             const double x = v0 + ix * dv;
             double Sx, Sy;
-            bicubic_sample_grad(F, nv, pitch, v0, dv, idv, x * cb - y * sb, x * sb + y * cb, Sx, Sy);
+            bicubic_sample_grad(F, nv, pitch, idv, __builtin_fma((double)ix, cb, ul), __builtin_fma((double)ix, sb, vl), Sx, Sy);
             s1 += Sx * x + Sy * y;
             s2 += -Sx * y + Sy * x;
           }
@@ -1909,11 +1966,12 @@ __global__ __launch_bounds__(kG2 * kThreads) void k_form_factor_2d_adj(KStatic S
       } else {
         for (int iy = gt; iy < nv; iy += kThreads) {
           const double y = v0 + iy * dv;
-          double s1 = 0.0, s2 = 0.0;
+          double s1 = 0.0, s2 = 0.0, ul, vl;
+          line_origin(cb, sb, y, v0, idv, ul, vl);
           for (int ix = 0; ix < nv; ++ix) {
             const double x = v0 + ix * dv;
             double Sx, Sy;
-            bicubic_sample_grad(F, nv, pitch, v0, dv, idv, x * cb - y * sb, x * sb + y * cb, Sx, Sy);
+            bicubic_sample_grad(F, nv, pitch, idv, __builtin_fma((double)ix, cb, ul), __builtin_fma((double)ix, sb, vl), Sx, Sy);
             s1 += Sx * x + Sy * y;
             s2 += -Sx * y + Sy * x;
           }
@@ -2016,16 +2074,17 @@ __global__ __launch_bounds__(4 * kThreads) void k_ff2d_table_adj(int nv, const d
         line_range(cb, (cb * v0 - y * sb - v0) * idv, (double)cx0, (double)cx1, cx0 == 0, cx1 == ncell, ix0, ix1);
         line_range(sb, (sb * v0 + y * cb - v0) * idv, (double)cy0, (double)cy1, cy0 == 0, cy1 == ncell, ix0, ix1);
       }
+      double ul, vl;
+      line_origin(cb, sb, y, v0, idv, ul, vl);
       for (int ix = ix0; ix < ix1; ++ix) {
-        const double x = v0 + ix * dv;
-        const double xq = x * cb - y * sb, yq = x * sb + y * cb;
-        int cx = (int)floor((xq - v0) * idv), cy = (int)floor((yq - v0) * idv);
-        cx = cx < 0 ? 0 : (cx > nv - 2 ? nv - 2 : cx);
-        cy = cy < 0 ? 0 : (cy > nv - 2 ? nv - 2 : cy);
+        int cx, cy;
+        double tx, ty;
+        cell_of(__builtin_fma((double)ix, cb, ul), nv, cx, tx);
+        cell_of(__builtin_fma((double)ix, sb, vl), nv, cy, ty);
         if (!whole && (cx < cx0 || cx >= cx1 || cy < cy0 || cy >= cy1)) continue;
         double wx[4], wy[4];
-        catmull_rom((xq - (v0 + cx * dv)) * idv, wx);
-        catmull_rom((yq - (v0 + cy * dv)) * idv, wy);
+        catmull_rom(tx, wx);
+        catmull_rom(ty, wy);
         double* q0 = T + (size_t)(cx - cx0) * pitch + (cy - cy0);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
