@@ -519,9 +519,11 @@ __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& 
 }
 
 // P(lambda_j, theta_a) of one gradient point (form_factor.py:247-296)
+// point_forward_sd: S (1 + 2 w/w_L) -- everything but the factor pref ws^2, which k_spectrum applies once per angle
+// (pref) and once per wavelength sample (ws^2) instead of once per point
 template <int NI>
-__device__ __forceinline__ double point_forward(double ws, const Base& b, const Base& bn, bool has_next,
-                                                const LineS<NI>& L, const Tables& T) {
+__device__ __forceinline__ double point_forward_sd(const Base& b, const Base& bn, bool has_next, const LineS<NI>& L,
+                                                   const Tables& T) {
   const double ik2 = b.ik * b.ik;
   const double ike2 = L.a_e * ik2;
   const double vph = b.wd * b.ik;
@@ -546,23 +548,30 @@ __device__ __forceinline__ double point_forward(double ws, const Base& b, const 
   const double ce2 = cer * cer + cei * cei;
   const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
   const double S = (gsum * ce2 + ci2 * b.F * L.ivTe) * b.ik * frcp(eps2);  // :282-288
-  return S * (1.0 + b.wd * L.i2wL) * L.pref * ws * ws;                     // :291-294
+  return S * (1.0 + b.wd * L.i2wL);                                        // :291
+}
+template <int NI>
+__device__ __forceinline__ double point_forward(double ws, const Base& b, const Base& bn, bool has_next,
+                                                const LineS<NI>& L, const Tables& T) {
+  return point_forward_sd<NI>(b, bn, has_next, L, T) * L.pref * ws * ws;   // :291-294
 }
 
 struct BaseAdj {  // adjoints flowing into base quantities of a point
   double k2, ik, wd, xe, F;
 };
 
-// reverse of point_forward: given Pbar, produce adjoints of this point's base quantities (ba),
+// reverse of point_forward: given the seed, produce adjoints of this point's base quantities (ba),
 // of the right neighbour's (xe, F) (xen, Fn), and accumulate lineout-scalar adjoints into LB.
 // GM: 0 plasma parameters only, 1 + DLM order m (tangent tables), 2 + the distribution-function tables themselves
+// PQ = Pbar pref ws^2 (the seed times the factor point_forward_sd leaves out)
 template <int NI, int GM = 0>
-__device__ __forceinline__ void point_reverse(double ws, const Base& b, const Base& bn, bool has_next,
-                                              const LineS<NI>& L, const Tables& T, double Pbar,
+__device__ __forceinline__ void point_reverse(const Base& b, const Base& bn, bool has_next,
+                                              const LineS<NI>& L, const Tables& T, double PQ,
                                               BaseAdj& ba, double& xen, double& Fn, LineS<NI>& LB, FeAcc& fa) {
   // ---- recompute forward ----
   const double ik2 = b.ik * b.ik;
   const double ike2 = L.a_e * ik2;
+  const double pike = kPi * ike2;
   const double vph = b.wd * b.ik;
   double cre = 0.0, cim = 0.0, gsum = 0.0;
   double xi[NI], zr[NI], zi[NI], dzr[NI], dzi[NI], iki2[NI], gs[NI];
@@ -579,32 +588,37 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
   w_lookup(T.W, b.xe, Wl, dW);
   const double idx = has_next ? frcp(bn.xe - b.xe) : 0.0;
   const double D = has_next ? (bn.F - b.F) * idx : 0.0;
-  const double cer = -ike2 * Wl, cei = kPi * ike2 * D;
-  const double er = 1.0 + cer + cre, ei = cei + cim;
+  const double cer = -ike2 * Wl, cei = pike * D;
+  const double opc = 1.0 + cre;
+  const double er = opc + cer, ei = cei + cim;
   const double eps2 = er * er + ei * ei, ieps2 = frcp(eps2);
   const double ce2 = cer * cer + cei * cei;
-  const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
+  const double ci2 = opc * opc + cim * cim;
   const double N = gsum * ce2 + ci2 * b.F * L.ivTe;
-  const double S = N * b.ik * ieps2;
+  const double t1 = b.ik * ieps2;
+  const double S = N * t1;
   const double dop = 1.0 + b.wd * L.i2wL;
-  const double Q = L.pref * ws * ws;
   // ---- reverse ----
-  const double Sb = Pbar * dop * Q;
-  const double PSQ = Pbar * S * Q;
-  ba.wd = PSQ * L.i2wL;
-  LB.wL -= PSQ * b.wd * (0.5 * L.i2wL * L.i2wL);
-  LB.pref += Pbar * S * dop * ws * ws;
-  const double Nb = Sb * b.ik * ieps2;
-  ba.ik = Sb * N * ieps2;
-  const double eps2b = -Sb * N * b.ik * ieps2 * ieps2;
-  const double ci2b = Nb * b.F * L.ivTe;
-  ba.F = Nb * ci2 * L.ivTe;
-  LB.ivTe += Nb * ci2 * b.F;
-  const double ce2b = Nb * gsum;
-  const double erb = eps2b * 2.0 * er, eib = eps2b * 2.0 * ei;
-  const double cerb = erb + ce2b * 2.0 * cer, ceib = eib + ce2b * 2.0 * cei;
-  const double creb = erb + ci2b * 2.0 * (1.0 + cre), cimb = eib + ci2b * 2.0 * cim;
-  double ike2b = -cerb * Wl + ceib * kPi * D;
+  // Accumulators with a DEFERRED wavefront-uniform factor (applied once per gradient point by lines_adjoint_finalize,
+  // instead of once per point): LB.pref holds sum Sb S (x 1/pref), LB.i2wL holds sum PSQ wd (-> LB.wL, x -i2wL^2/2),
+  // LB.a_i[s] holds sum (creb zr + cimb zi) ik2 (x -1/2).
+  const double Sb = PQ * dop;
+  const double PSQ = PQ * S;
+  LB.i2wL += PSQ * b.wd;
+  LB.pref += Sb * S;
+  const double Nb = Sb * t1;
+  const double ikb0 = Sb * N * ieps2;          // first part of the adjoint of 1/k
+  const double e2 = -2.0 * (ikb0 * t1);        // 2 x adjoint of |eps|^2
+  const double NbI = Nb * L.ivTe;
+  const double ci2b2 = 2.0 * (NbI * b.F);       // 2 x adjoint of |1 + chi_i|^2
+  ba.F = NbI * ci2;
+  LB.ivTe += (Nb * ci2) * b.F;
+  const double ce2b2 = 2.0 * (Nb * gsum);       // 2 x adjoint of |chi_e|^2
+  const double erb = e2 * er, eib = e2 * ei;
+  const double cerb = erb + ce2b2 * cer, ceib = eib + ce2b2 * cei;
+  const double creb = erb + ci2b2 * opc, cimb = eib + ci2b2 * cim;
+  const double cp = ceib * kPi;
+  const double ike2b = cp * D - cerb * Wl;
   const double Wlb = -cerb * ike2;  // adjoint of the interpolated W
   ba.xe = Wlb * dW;
   if (GM == 1) {  // W depends on the DLM order through the table itself
@@ -613,30 +627,41 @@ __device__ __forceinline__ void point_reverse(double ws, const Base& b, const Ba
     LB.m += Wlb * Wml;
   }
   if (GM == 2) fe_add_w(fa, T.Wb, b.xe, Wlb);
-  const double Db = ceib * kPi * ike2;
   // D = (Fn - F) * idx
-  Fn = Db * idx;
-  ba.F -= Db * idx;
-  xen = -Db * D * idx;
-  ba.xe += Db * D * idx;
-  double k2b = 0.0, vphb = 0.0;
+  Fn = (cp * ike2) * idx;
+  ba.F -= Fn;
+  xen = -Fn * D;
+  ba.xe -= xen;
+  double k2acc = 0.0, vphb = 0.0;
+  const double u = Nb * ce2;
 #pragma unroll
   for (int s = 0; s < NI; ++s) {
-    LB.cs[s] += Nb * ce2 * gs[s];
-    double xib = Nb * ce2 * L.cs[s] * gs[s] * (-2.0 * xi[s]);
-    const double iki2b = -0.5 * (creb * zr[s] + cimb * zi[s]);
-    xib += -0.5 * iki2[s] * (creb * dzr[s] + cimb * dzi[s]);
-    LB.a_i[s] += iki2b * ik2;
-    k2b -= iki2b * iki2[s] * ik2;
+    const double v = u * gs[s];
+    LB.cs[s] += v;
+    const double w = creb * zr[s] + cimb * zi[s];
+    const double xib = -2.0 * (v * xi[s] * L.cs[s]) - 0.5 * iki2[s] * (creb * dzr[s] + cimb * dzi[s]);
+    const double wk = w * ik2;
+    LB.a_i[s] += wk;
+    k2acc += wk * iki2[s];
     vphb += xib * L.ixi[s];
     LB.ixi[s] += xib * vph;
   }
-  LB.a_e += ike2b * ik2;
-  k2b -= ike2b * ike2 * ik2;
-  ba.k2 = k2b;
+  const double we = ike2b * ik2;
+  LB.a_e += we;
+  ba.k2 = 0.5 * k2acc - we * ike2;
   // v_ph = wd * ik
-  ba.wd += vphb * b.ik;
-  ba.ik += vphb * b.wd;
+  ba.wd = PSQ * L.i2wL + vphb * b.ik;
+  ba.ik = ikb0 + vphb * b.wd;
+}
+
+// the deferred factors of point_reverse (see there), applied to a thread's (or a reduced) accumulator set
+template <int NI>
+__device__ __forceinline__ void lines_adjoint_finalize(const LineS<NI>& L, LineS<NI>& LB) {
+  LB.pref *= 1.0 / L.pref;
+  LB.wL -= LB.i2wL * (0.5 * L.i2wL * L.i2wL);
+  LB.i2wL = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) LB.a_i[s] *= -0.5;
 }
 
 // reverse of base_eval
@@ -664,11 +689,11 @@ __device__ __forceinline__ void base_reverse(double ct, const Base& b, const Lin
   // wd = ws - wL - k Vd
   LB.wL -= wdb;
   LB.Vd -= wdb * k;
-  // k = sqrt(k2), ik = 1/k
-  const double kb = -wdb * L.Vd - ikb * b.ik * b.ik;
-  const double k2b = ba.k2 + kb * 0.5 * b.ik;
-  const double ksb = k2b * 2.0 * (b.ks - L.kL * ct);
-  LB.kL += k2b * 2.0 * (L.kL - b.ks * ct);
+  // k = sqrt(k2), ik = 1/k:  kb = -wdb Vd - ikb ik^2,  k2b = ba.k2 + kb ik / 2
+  const double kb = wdb * L.Vd + ikb * (b.ik * b.ik);
+  const double k22 = 2.0 * ba.k2 - kb * b.ik;     // 2 x adjoint of k^2
+  const double ksb = k22 * (b.ks - L.kL * ct);
+  LB.kL += k22 * (L.kL - b.ks * ct);
   LB.wpe2 -= ksb * (0.5 / (kC * kC)) * frcp(b.ks);
 }
 

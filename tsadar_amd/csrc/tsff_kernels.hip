@@ -821,7 +821,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       // chunk, the others one iteration ahead of their use so the load latency hides behind a whole point
       const double ws_first = omgs[j0], ws_second = omgs[min(j0 + 1, npts - 1)];
       for (int a = 0; a < NA; ++a) {
-        const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a] * invG);
+        const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a] * invG * L.pref);   // (pref: see point_forward_sd)
         double ws = ws_first, wnext = ws_second;
         Base b0;
         base_eval<NI>(ws, use_ks ? ksc[j0] : ks_eval(ws, L.wpe2), ct, L, T, b0);
@@ -833,19 +833,24 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
           wnext = omgs[min(j + 2, npts - 1)];
           Base b1;
           base_eval<NI>(wsn, use_ks ? ksc[min(j + 1, npts - 1)] : ks_eval(wsn, L.wpe2), ct, L, T, b1);
-          xs[XA(j)] += wa * point_forward<NI>(ws, b0, b1, has_next, L, T);
+          xs[XA(j)] += wa * point_forward_sd<NI>(b0, b1, has_next, L, T);
           b0 = b1;
           ws = wsn;
         }
       }
     }
   }
-  if (f == TSFF_FEATURE_ELE && S.filt)
+  {  // the factor ws^2 of every sample (left out of the sweep) and the notch filter of the electron feature
+    const bool filt = f == TSFF_FEATURE_ELE && S.filt;
     for (int st = ht; st < nstrips; st += TPF) {
       const int j0 = kStrip * st;
 #pragma unroll
-      for (int q = 0; q < kStrip; ++q) xs[XA(j0 + q)] *= S.filt[j0 + q];
+      for (int q = 0; q < kStrip; ++q) {
+        const double w = omgs[j0 + q];
+        xs[XA(j0 + q)] *= filt ? w * w * S.filt[j0 + q] : w * w;
+      }
     }
+  }
   __syncthreads();
 
   // ================= IRF convolution ("same"), bin average, normalisation =================
@@ -994,7 +999,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * ht + r;
-      double v = sx[r];
+      double v = sx[r] * (omgs[i] * omgs[i]);   // (the seed of the reverse sweep carries ws^2, see point_reverse)
       if (f == TSFF_FEATURE_ELE && S.filt) v *= S.filt[i];
       xs[XA(i)] = v * invG;
     }
@@ -1012,7 +1017,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
 #pragma unroll
     for (int r = 0; r < BPT; ++r) {
       const int i = ht + TPF * r;
-      double v = sx[r];
+      double v = sx[r] * (omgs[i] * omgs[i]);
       if (f == TSFF_FEATURE_ELE && S.filt) v *= S.filt[i];
       xs[H + i] = v * invG;
     }
@@ -1022,6 +1027,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       int pb = q / ppp;
       double sv = 0.0;
       for (int t = q - pb * ppp; t < nh; t += ppp, --pb) sv += taps[t] * ybs[Hb + pb];
+      sv *= omgs[i] * omgs[i];
       if (f == TSFF_FEATURE_ELE && S.filt) sv *= S.filt[i];
       xs[H + i] = sv * invG;
     }
@@ -1059,7 +1065,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
       const int j0 = kStrip * st;
       const double ws_first = omgs[j0], ws_second = omgs[min(j0 + 1, npts - 1)];
       for (int a = 0; a < NA; ++a) {
-        const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a]);
+        const double ct = uni(m.cosa[a]), wa = uni(m.wsa[a] * L.pref);
         double ws = ws_first, wnext = ws_second;
         Base b0;
         base_eval<NI>(ws, use_ks ? ksc[j0] : ks_eval(ws, L.wpe2), ct, L, T, b0);
@@ -1074,7 +1080,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
           base_eval<NI>(wsn, use_ks ? ksc[min(j + 1, npts - 1)] : ks_eval(wsn, L.wpe2), ct, L, T, b1);
           BaseAdj ba;
           double xen, Fn;
-          point_reverse<NI, GM>(ws, b0, b1, has_next, L, T, xs[XA(j)] * wa, ba, xen, Fn, LB, fa);
+          point_reverse<NI, GM>(b0, b1, has_next, L, T, xs[XA(j)] * wa, ba, xen, Fn, LB, fa);
           ba.xe += cxe; ba.F += cF;
           base_reverse<NI, GM>(ct, b0, L, T, ba, LB, fa);
           cxe = xen; cF = Fn;
@@ -1091,6 +1097,7 @@ __global__ __launch_bounds__(2 * kHalf, TSFF_OCC) void k_spectrum(KStatic S, KCa
     // ---- reduce the lineout-scalar adjoints over the feature's 4 wavefronts; one thread per feature
     //      chains them to the physical parameters (make_lines_adjoint) ----
     {
+      lines_adjoint_finalize<NI>(L, LB);   // deferred wavefront-uniform factors of point_reverse
       double lb[NLB];
       lb[0] = LB.wpe2; lb[1] = LB.wL; lb[2] = LB.kL; lb[3] = LB.ivTe; lb[4] = LB.a_e; lb[5] = LB.pref; lb[6] = LB.Ud; lb[7] = LB.Vd;
 #pragma unroll
@@ -1301,8 +1308,8 @@ __global__ __launch_bounds__(kThreads) void k_form_factor_adj(KStatic S, KCall K
           if (j < npts) {
             BaseAdj ba;
             double xen, Fn;
-            point_reverse<NI, GM>(ws[q], b0, b1, has_next, L, T, Pbar[(((size_t)b * G + g) * npts + j) * NA + a], ba, xen, Fn,
-                                  LB, fa);
+            point_reverse<NI, GM>(b0, b1, has_next, L, T,
+                                  Pbar[(((size_t)b * G + g) * npts + j) * NA + a] * (L.pref * ws[q] * ws[q]), ba, xen, Fn, LB, fa);
             ba.xe += cxe; ba.F += cF;
             base_reverse<NI, GM>(ct, b0, L, T, ba, LB, fa);
             cxe = xen; cF = Fn;
@@ -1316,6 +1323,7 @@ __global__ __launch_bounds__(kThreads) void k_form_factor_adj(KStatic S, KCall K
         }
       }
     }
+    lines_adjoint_finalize<NI>(L, LB);   // deferred wavefront-uniform factors of point_reverse
     double lb[NLB];
     lb[0] = LB.wpe2; lb[1] = LB.wL; lb[2] = LB.kL; lb[3] = LB.ivTe; lb[4] = LB.a_e; lb[5] = LB.pref; lb[6] = LB.Ud; lb[7] = LB.Vd;
 #pragma unroll
