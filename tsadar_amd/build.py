@@ -8,8 +8,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "tsff_kernels.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "tsff_device.h"), os.path.join(_HERE, "csrc", "tsff_api.inc"),
-        os.path.join(ROOT, "include", "tsff.h")]
+DEPS = [os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc")))] + [
+    os.path.join(ROOT, "include", "tsff.h")]  # one translation unit: tsff_kernels.hip includes every .h / .inc of csrc/
 OUT = os.path.join(_HERE, "libtsff.so")
 
 
