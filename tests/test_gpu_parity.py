@@ -857,6 +857,28 @@ def _dist_rank_2d(rank, world, port, out):
     gp, gf = D.form_factor_2d_grad_sharded(eng, 0, tp.physical_matrix(), fe2, Pbar, 25.0, -40.0, world, rank)
     gp1, gf1 = eng.form_factor_2d_grad(0, tp.physical_matrix(), fe2, Pbar, 25.0, -40.0)
     np.savez(os.path.join(out, f"g{rank}.npz"), gp=gp.cpu().numpy(), gf=gf.cpu().numpy(), gp1=gp1.cpu().numpy(), gf1=gf1.cpu().numpy())
+    # the whole angular fit step on two ranks: LossFunction(distributed=True) shards the point list of the 2-D form factor
+    # (all-gather) and of its adjoint (all-reduce); value and gradient equal the single-rank ones
+    from tsadar_amd import tree
+    from tsadar_amd.loss_function import LossFunction
+
+    acfg = decks.deck_angular(2, 48, (128, 256), 10, 110)
+    asa = _angular_sa(acfg)
+    atp = ThomsonParams(acfg["parameters"], 1, batch=False, activate=True)
+    abatch = dict(e_data=np.ones((100, 256)), i_data=np.zeros((100, 256)), e_amps=np.ones((100, 1)), i_amps=np.zeros(100),
+                  noise_e=np.array([0.0]), noise_i=np.array([0.0]))
+    single = LossFunction(acfg, asa, abatch)
+    truth = atp.copy()
+    truth.X[0, 0] -= 0.3
+    abatch["e_data"] = single.ts_diag(truth, abatch)[0]
+    single = LossFunction(acfg, asa, abatch)
+    multi = LossFunction(acfg, asa, abatch, distributed=True)
+    adiff, astatic = tree.partition(atp, tree.get_filter_spec(acfg["parameters"], atp))
+    x0, single.unravel_weights = tree.ravel_pytree(adiff)
+    multi.unravel_weights = single.unravel_weights
+    v1, g1 = single.vg_loss(x0, astatic, abatch)
+    v2, g2 = multi.vg_loss(x0, astatic, abatch)
+    np.savez(os.path.join(out, f"a{rank}.npz"), v1=v1, g1=g1, v2=v2, g2=g2)
     dist.destroy_process_group()
 
 
@@ -881,6 +903,9 @@ def test_two_rank_sharded_form_factor_2d(torch_mod, tmp_path):
     np.testing.assert_array_equal(p1[0], p1[1])
     np.testing.assert_array_equal(p0[0], p1[0])
     g0, g1 = np.load(tmp_path / "g0.npz"), np.load(tmp_path / "g1.npz")
+    a0, a1 = np.load(tmp_path / "a0.npz"), np.load(tmp_path / "a1.npz")
+    assert a0["v2"] == a1["v2"] == a0["v1"] and np.array_equal(a0["g2"], a1["g2"])   # forward bit-identical, ranks agree
+    assert a0["g1"].size == 48 * 48 + 5 and np.max(np.abs(a0["g2"] - a0["g1"])) < 1e-10 * np.max(np.abs(a0["g1"]))
     for k in ("gp", "gf"):   # sums in a different order: equal to rounding, identical on both ranks
         np.testing.assert_array_equal(g0[k], g1[k])
         assert np.max(np.abs(g0[k] - g0[k + "1"])) < 1e-11 * np.max(np.abs(g0[k + "1"])), k

@@ -28,6 +28,9 @@ class ThomsonScatteringDiagnostic:
         else:
             raise NotImplementedError(f"Unknown spectype: {spectype}")  # thomson_diagnostic.py:40
         self._engines = {}
+        # (world, rank, process group) when the (lambda, theta) point list of a 2-D angular deck is sharded over the GPUs
+        # of a node (parallel_calc_all_chi_vals, form_factor.py:431-447); set by LossFunction(distributed=True)
+        self.dist = None
 
     def engine(self, activate: bool) -> Engine:
         """One engine per activation mode (the sigmoid flags are static configuration)."""
@@ -76,7 +79,12 @@ class ThomsonScatteringDiagnostic:
         if eng.fe_dim == 2:
             gen = cfg["parameters"]["general"]
             fe2 = eng.dev(np.ascontiguousarray(ts_params()["electron"]["fe"], dtype=np.float64))
-            P = eng.form_factor_2d(0, phys, fe2, gen["ud"]["angle"], gen["Va"]["angle"])
+            if self.dist is not None and self.dist[0] > 1:
+                from . import distributed as D
+
+                P = D.form_factor_2d_sharded(eng, 0, phys, fe2, gen["ud"]["angle"], gen["Va"]["angle"], *self.dist)
+            else:
+                P = eng.form_factor_2d(0, phys, fe2, gen["ud"]["angle"], gen["Va"]["angle"])
         else:
             fe1 = np.ascontiguousarray(np.asarray(ts_params()["electron"]["fe"], dtype=np.float64).reshape(1, -1))
             P = eng.form_factor(0, phys, fe1)

@@ -33,13 +33,19 @@ class LossFunction:
         if self.multiplex_ang:
             raise NotImplementedError("multiplexed angular fits are outside the 1-D form-factor path")
         self.angular = "angular" in cfg["other"]["extraoptions"]["spectype"]
-        if self.angular and distributed:
-            raise NotImplementedError("angular fits evaluate one plasma condition: nothing to shard over lineouts")
+        if self.angular and distributed and int(cfg["parameters"]["electron"].get("fe", {}).get("dim", 1)) != 2:
+            raise NotImplementedError("1-D angular fits evaluate one plasma condition in a millisecond: nothing to shard")
         self.fd_step = 1e-5  # normalised units; central differences of the 1-D angular model (see _vg_angular)
         self.force_fd = False  # True: central differences for 2-D distribution functions too (cross-check of the adjoint)
         self.ts_diag = ThomsonScatteringDiagnostic(cfg, scattering_angles=scattering_angles)
         self.distributed = distributed
         self.pg = process_group
+        if self.angular and distributed:
+            # 2-D angular decks: every rank holds the whole (single) plasma condition; the (lambda, theta) point list of the
+            # form factor and of its adjoint is what gets sharded (one all-gather forward, one all-reduce backward)
+            import torch.distributed as dist
+
+            self.ts_diag.dist = (dist.get_world_size(process_group), dist.get_rank(process_group), process_group)
         self.unravel_weights = None  # set by the caller exactly as in loops.py:41
         self._gfe = None
         self._dev_batch_key = None
@@ -172,8 +178,12 @@ class LossFunction:
         gfe_h = None
         if ts_params.fe_dim == 2:
             want_table = any(s in (tree.GEN2D_SLOT, tree.FVAL2D_SLOT) for _, s in diff_weights.slots)
-            gp, gfe = eng.form_factor_2d_grad(0, phys, ctx["fe2"], Pbar.reshape(P.shape), gen["ud"]["angle"], gen["Va"]["angle"],
-                                              want_table=want_table)
+            if self.ts_diag.dist is not None and self.ts_diag.dist[0] > 1:
+                gp, gfe = D.form_factor_2d_grad_sharded(eng, 0, phys, ctx["fe2"], Pbar.reshape(P.shape), gen["ud"]["angle"],
+                                                        gen["Va"]["angle"], *self.ts_diag.dist, want_table=want_table)
+            else:
+                gp, gfe = eng.form_factor_2d_grad(0, phys, ctx["fe2"], Pbar.reshape(P.shape), gen["ud"]["angle"],
+                                                  gen["Va"]["angle"], want_table=want_table)
         else:
             want_fe = any(s in (tree.FVAL_SLOT, L.P_M) for _, s in diff_weights.slots)
             gp, gfe = eng.form_factor_grad(0, phys, ctx["fe1"], Pbar.reshape(P.shape), want_fe=want_fe)
