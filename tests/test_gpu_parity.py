@@ -1409,3 +1409,30 @@ def test_form_factor_grad_finite_differences(torch_mod, n_ion, G):
                 fm[b, i] -= h
                 fd = (J(X, fp) - J(X, fm)) / (2 * h)
                 assert abs(gf[b, i] - fd) * fe[b, i] < 1e-4 * max(abs(fd) * fe[b, i], 1e-3 * np.max(np.abs(glog[ok]))), (feature, b, i, gf[b, i], fd)
+
+
+def test_committed_golden_fixture_2d(torch_mod):
+    """tests/golden/oracle_2d.npz (made by tests/golden/make_golden_2d.py from the CPU oracle alone): the 2-D form factor on
+    a 48 x 48 anisotropic table (both features, oblique drift and flow) and the ARTS image of a 1-D DLM deck through the
+    drop-in ThomsonScatteringDiagnostic -- the committed regression pin of the angular path."""
+    from tsadar_amd import ThomsonParams
+    from tsadar_amd.diagnostic import ThomsonScatteringDiagnostic
+
+    z = np.load("tests/golden/oracle_2d.npz")
+    cfg = decks.deck_fit()
+    sa = dict(sa=z["ff_sa"], weights=np.ones((2, 3)) / 3)
+    eng = _engine(cfg, sa)
+    for feature in (0, 1):
+        P = eng.form_factor_2d(feature, z["ff_X"], z["ff_fe2d"], float(z["ff_ud_angle"]), float(z["ff_va_angle"])).cpu().numpy()
+        ref = z[f"ff_P{feature}"]
+        err = np.max(np.abs(P[:, :, z["ff_idx"], :] - ref) / np.abs(ref))
+        assert err < 1e-7, (feature, err)
+    acfg = decks.deck_angular(1, 64, (128, 256), 10, 110)
+    asa = _angular_sa(acfg)
+    diag = ThomsonScatteringDiagnostic(acfg, asa)
+    tp = ThomsonParams(acfg["parameters"], 1, batch=False, activate=True)
+    batch = dict(e_data=np.ones((100, 256)), i_data=np.zeros((100, 256)), e_amps=z["ats_e_amps"], i_amps=np.zeros(100),
+                 noise_e=np.array([0.0]), noise_i=np.array([0.0]))
+    E, _, lamE, _ = diag(tp, batch)
+    assert E.shape == z["ats_E"].shape and np.max(np.abs(E - z["ats_E"])) < 1e-8 * np.max(np.abs(z["ats_E"]))
+    np.testing.assert_allclose(lamE, z["ats_lam"], rtol=1e-13)
