@@ -1436,3 +1436,39 @@ def test_committed_golden_fixture_2d(torch_mod):
     E, _, lamE, _ = diag(tp, batch)
     assert E.shape == z["ats_E"].shape and np.max(np.abs(E - z["ats_E"])) < 1e-8 * np.max(np.abs(z["ats_E"]))
     np.testing.assert_allclose(lamE, z["ats_lam"], rtol=1e-13)
+
+
+def test_angular_optax_loop_like_reference(torch_mod):
+    """The reference's angular fit loop (inverse/loops.py:167-275: batch=False parameters, optax Adam on the partitioned
+    pytree, ``(val, aux), grad = loss_fn.vg_loss(diff_params, static_params, data)``) on an ARTS deck whose distribution
+    function is a free-form 48 x 48 table: data from a different table (another super-Gaussian order) and temperature;
+    the loop -- all 2304 table values and the plasma parameters trained together through the adjoint -- lowers the loss."""
+    from tsadar_amd import ThomsonParams, tree
+    from tsadar_amd import distribution as Dist
+    from tsadar_amd.loss_function import LossFunction
+
+    nvx = 48
+    cfg = decks.deck_angular(2, nvx, (128, 256), 10, 110)
+    cfg["optimizer"]["method"] = "adam"
+    cfg["optimizer"]["learning_rate"] = 0.001   # (0.004: 22 x lower loss in 60 steps; 0.01 oscillates)
+    sa = _angular_sa(cfg)
+    tp = ThomsonParams(cfg["parameters"], 1, batch=False, activate=True)
+    truth = tp.copy()
+    truth.X[0, L.P_TE] -= 0.3
+    truth.fval2d = Dist.arbitrary_2v_init(3.2, nvx, truth.learn_log)
+    batch = dict(e_data=np.ones((100, 256)), i_data=np.zeros((100, 256)), e_amps=np.ones((100, 1)), i_amps=np.zeros(100),
+                 noise_e=np.array([0.0]), noise_i=np.array([0.0]))
+    batch["e_data"] = LossFunction(cfg, sa, batch).ts_diag(truth, batch)[0]
+    loss_fn = LossFunction(cfg, sa, batch)
+    diff, static = tree.partition(tp, tree.get_filter_spec(cfg["parameters"], tp))
+    assert any(v.size == nvx * nvx for v in diff.values)
+    opt = tree.Adam(cfg["optimizer"]["learning_rate"])
+    state = opt.init(diff)
+    losses = []
+    for _ in range(40):
+        (val, aux), grad = loss_fn.vg_loss(diff, static, batch)
+        assert isinstance(grad, tree.DiffParams) and aux[0].shape == (100, 256) and aux[1]["electron"]["fe"].shape == (nvx, nvx)
+        updates, state = opt.update(grad, state)
+        diff = tree.apply_updates(diff, updates)
+        losses.append(val)
+    assert losses[-1] < 0.4 * losses[0] and max(losses) <= 1.05 * losses[0], losses
