@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TSFF_ABI_VERSION 4
+#define TSFF_ABI_VERSION 5
 
 /* ---- parameter slots of one lineout: params[b][TSFF_NP(n_ion)] (normalised leaves of the
  * reference's ThomsonParams pytree, core/modules/ts_params.py:49-60,395-420,253-262) ---------- */

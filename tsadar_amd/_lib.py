@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsff.so")
 LIB_PATH = os.environ.get("TSFF_LIBRARY", LIB_PATH)  # A/B experiments: another in-tree build of the same ABI
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_ION = 4
 NBINS = 1024
 NXI1 = 1024
