@@ -17,6 +17,11 @@
  *     add_ion_IRF / add_electron_IRF core/physics/irf.py:50-132
  *   LossFunction.vg_loss / __loss__ inverse/loss_function.py:128-168,364-373  tsff_loss_grad
  *   LossFunction.array_loss (post_loss) inverse/loss_function.py:375-384      tsff_array_loss
+ *   FormFactor.calc_in_2D / rotate / calc_chi_vals  core/physics/form_factor.py:300-587   tsff_form_factor_2d(_range)
+ *   angular_full electron_spectrum, add_ATS_IRF, reduce_ATS_to_resunit
+ *       generate_spectra.py:193-216, irf.py:5-47, thomson_diagnostic.py:78-107           tsff_ats_setup / tsff_ats_spectrum
+ *   jax reverse mode through the above (equinox.filter_value_and_grad, loss_function.py:108)
+ *       tsff_loss_grad(_fe), tsff_form_factor_grad, tsff_form_factor_2d_grad, tsff_ats_adjoint
  *
  * Conventions
  *   - every array pointer in a *call* is a DEVICE pointer (hipMalloc'ed or a torch CUDA tensor);
@@ -180,7 +185,7 @@ int tsff_form_factor_grad(tsff_handle *h, int32_t feature, const double *phys, c
  * for a 2-D electron distribution fe2d[nv][nv] on the grid linspace(-6 + dv/2, 6 - dv/2, nv) (first index = v_x;
  * one table shared by all lineouts when shared_fe != 0, else [B][nv][nv]): P[B][G][npts][n_angles].  `phys` holds
  * PHYSICAL parameters [B][NP]; ud_angle / va_angle are the drift and flow directions in degrees
- * (parameters.general.ud.angle / Va.angle).  Forward only.  Parity with the reference is unpinned for this entry:
+ * (parameters.general.ud.angle / Va.angle).  Its adjoint is tsff_form_factor_2d_grad.  Parity with the reference is unpinned for this entry:
  * its golden vectors are not part of the reference source tree. */
 int tsff_form_factor_2d(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
                         int32_t shared_fe, double ud_angle_deg, double va_angle_deg, int32_t B, double *P);
