@@ -8,7 +8,7 @@ from tsadar_amd.engine import Engine
 from tsadar_amd.loss_function import LossFunction
 from tsadar_amd.calibration import sa_lookup
 
-B = 4096
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = S.baseline_deck(batch_size=B)
 sa = sa_lookup("P9"); sa = dict(sa=sa["sa"], weights=sa["weights"] * np.ones([B, 10]))
 eng = Engine(cfg, sa)
