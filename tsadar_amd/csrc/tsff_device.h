@@ -392,9 +392,6 @@ __device__ __forceinline__ void make_lines_adjoint(const Phys<NI>& p, double lam
 #ifndef TSFF_FEXP
 #define TSFF_FEXP 1
 #endif
-#ifndef TSFF_FASTPATH
-#define TSFF_FASTPATH 0  // wavefront-uniform ion fast paths: measured slower (extra control flow), kept for experiments
-#endif
 __device__ __forceinline__ double fexp(double x) {
 #if !TSFF_FEXP
   return exp(x);
@@ -478,50 +475,52 @@ __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const
 
 // ion terms of one species at normalised phase velocity xi (form_factor.py:243-249, 277-280):
 // Z'(xi) = jnp.interp(xi, xi2, Zp, left=xi**-2 / 0, right=xi**-2 / 0) with its slope, and
-// gs = exp(-xi^2)/sqrt(2 pi).  (TSFF_FASTPATH: optional wavefront-uniform shortcuts -- the EPW window is
-// almost entirely beyond the Z' table and far enough for exp(-xi^2) to vanish, the IAW window almost
-// entirely inside the table; measured slower than the branch-free form, off by default.)
+// gs = exp(-xi^2)/sqrt(2 pi).
+// The table is held for xi >= 0 only (kNZh = 821 nodes 0, 0.01, ..., 8.2): the shipped rdWT / idWT data are exactly even
+// (Re Z') and odd (Im Z') -- tsff_create verifies it -- so Z'(xi) = (Re Z'(|xi|), sign(xi) Im Z'(|xi|)) and the slopes
+// pick up the opposite parity.  The table's own domain stays the reference's asymmetric [-8.2, 8.19] (arange): outside
+// it the asymptote applies.  13 KB of LDS per workgroup less than the full table.
+// ZH = false: the full 1640-node table (no sign handling: about 1 % fewer instructions per point); the spectrum kernels
+// use it whenever the LDS budget does not need the 13 KB back (launch_spectrum decides).
+constexpr int kNZh = kNXi2 / 2 + 1;
+template <bool ZH = true>
 __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& zr, double& zi, double& dzr,
                                           double& dzi, double& gs) {
-#if TSFF_FASTPATH
-  const double ax = fabs(xi);
-  if (__all(ax > 28.0)) {
-    const double i2 = frcp(xi * xi);
-    zr = i2; zi = 0.0; dzr = -2.0 * i2 * i2 * xi; dzi = 0.0; gs = 0.0;
-    return;
-  }
-#endif
   gs = fexp(-xi * xi) * kInvSqrt2Pi;
   const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
-  const double u = (xi - kXi2_0) * kXi2_ih;
-  int i = (int)u;
-  i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
-  const double t = (xi - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
-  const double2 a = zp[i], b = zp[i + 1];
-  const double dr = b.x - a.x, di = b.y - a.y;
-  zr = a.x + t * dr; zi = a.y + t * di; dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
+  if (ZH) {
+    const double ax = fabs(xi);
+    int i = (int)(ax * kXi2_ih);
+    i = i > kNZh - 2 ? kNZh - 2 : i;
+    const double t = (ax - i * kXi2_h) * kXi2_ih;
+    const double2 a = zp[i], b = zp[i + 1];
+    const double dr = b.x - a.x, di = b.y - a.y;
+    // odd parts take the sign of xi: one AND and two XORs on the high words instead of compare + selects
+    const int sx = __double2hiint(xi) & (int)0x80000000;
+    const double zia = a.y + t * di, dzra = dr * kXi2_ih;
+    zr = a.x + t * dr; dzi = di * kXi2_ih;
+    zi = __hiloint2double(__double2hiint(zia) ^ sx, __double2loint(zia));
+    dzr = __hiloint2double(__double2hiint(dzra) ^ sx, __double2loint(dzra));
+  } else {
+    int i = (int)((xi - kXi2_0) * kXi2_ih);
+    i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
+    const double t = (xi - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
+    const double2 a = zp[i], b = zp[i + 1];
+    const double dr = b.x - a.x, di = b.y - a.y;
+    zr = a.x + t * dr; zi = a.y + t * di; dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
+  }
   const bool out = xi < kXi2_0 || xi > xlast;
-#if TSFF_BRANCHFREE
-  {
-    const double i2 = frcp(xi * xi);
-    const double di2 = -2.0 * i2 * i2 * xi;
-    zr = out ? i2 : zr; zi = out ? 0.0 : zi; dzr = out ? di2 : dzr; dzi = out ? 0.0 : dzi;
-  }
-#else
-#if TSFF_FASTPATH
-  if (__any(out))
-#endif
-  {
-    const double i2 = frcp(xi * xi);
-    if (out) { zr = i2; zi = 0.0; dzr = -2.0 * i2 * i2 * xi; dzi = 0.0; }
-  }
-#endif
+  // straight-line form (selects instead of branches: one scheduling region per point; wavefront-uniform shortcuts for the
+  // far EPW window and for the in-table IAW window were both measured slower)
+  const double i2 = frcp(xi * xi);
+  const double di2 = -2.0 * i2 * i2 * xi;
+  zr = out ? i2 : zr; zi = out ? 0.0 : zi; dzr = out ? di2 : dzr; dzi = out ? 0.0 : dzi;
 }
 
 // P(lambda_j, theta_a) of one gradient point (form_factor.py:247-296)
 // point_forward_sd: S (1 + 2 w/w_L) -- everything but the factor pref ws^2, which k_spectrum applies once per angle
 // (pref) and once per wavelength sample (ws^2) instead of once per point
-template <int NI>
+template <int NI, bool ZH = true>
 __device__ __forceinline__ double point_forward_sd(const Base& b, const Base& bn, bool has_next, const LineS<NI>& L,
                                                    const Tables& T) {
   const double ik2 = b.ik * b.ik;
@@ -532,7 +531,7 @@ __device__ __forceinline__ double point_forward_sd(const Base& b, const Base& bn
   for (int s = 0; s < NI; ++s) {
     const double xi = vph * L.ixi[s];                      // :243
     double zr, zi, dzr, dzi, gs;
-    ion_terms(T.zp, xi, zr, zi, dzr, dzi, gs);
+    ion_terms<ZH>(T.zp, xi, zr, zi, dzr, dzi, gs);
     const double iki2 = L.a_i[s] * ik2;
     cre -= 0.5 * iki2 * zr;                                // :249
     cim -= 0.5 * iki2 * zi;
@@ -564,7 +563,7 @@ struct BaseAdj {  // adjoints flowing into base quantities of a point
 // of the right neighbour's (xe, F) (xen, Fn), and accumulate lineout-scalar adjoints into LB.
 // GM: 0 plasma parameters only, 1 + DLM order m (tangent tables), 2 + the distribution-function tables themselves
 // PQ = Pbar pref ws^2 (the seed times the factor point_forward_sd leaves out)
-template <int NI, int GM = 0>
+template <int NI, int GM = 0, bool ZH = true>
 __device__ __forceinline__ void point_reverse(const Base& b, const Base& bn, bool has_next,
                                               const LineS<NI>& L, const Tables& T, double PQ,
                                               BaseAdj& ba, double& xen, double& Fn, LineS<NI>& LB, FeAcc& fa) {
@@ -578,7 +577,7 @@ __device__ __forceinline__ void point_reverse(const Base& b, const Base& bn, boo
 #pragma unroll
   for (int s = 0; s < NI; ++s) {
     xi[s] = vph * L.ixi[s];
-    ion_terms(T.zp, xi[s], zr[s], zi[s], dzr[s], dzi[s], gs[s]);
+    ion_terms<ZH>(T.zp, xi[s], zr[s], zi[s], dzr[s], dzi[s], gs[s]);
     iki2[s] = L.a_i[s] * ik2;
     cre -= 0.5 * iki2[s] * zr[s];
     cim -= 0.5 * iki2[s] * zi[s];

@@ -25,7 +25,8 @@ struct KStatic {
   const double* cos_sa;      // [n_angles]
   const double* sa_rad;      // [n_angles] scattering angles in radians (2-D path)
   const double* w_sa;        // [n_angles]
-  const double2* zp;         // [1640]
+  const double2* zp;         // [kNZh] Z' table for xi >= 0 (ion_terms)
+  const double2* zpf;        // [1640] the full table (spectrum kernels, when LDS allows)
   const double* xi1;         // [1024]
   const double* xi2;         // [1640]
   const double* taps[2];
