@@ -259,8 +259,8 @@ def main():
             "traffic": traffic,
             "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % (os.path.basename(tfile) if tfile else "-"),
             "algorithmic_bytes_per_launch": B * abytes,
-            "kernel": ("k_spectrum<1,0,0,256>" if args.forward_only else "k_spectrum<1,1,GM,256> (fused features)" if variant
-                       else "k_spectrum<1,1,0,256> (one launch of 2B 256-thread workgroups)"),
+            "kernel": ("k_spectrum<1,0,0,256,false>" if args.forward_only else "k_spectrum<1,1,GM,256,false> (one launch of 2B 256-thread workgroups)" if variant
+                       else "k_spectrum<1,1,0,256,false> (one launch of 2B 256-thread workgroups)"),
             "kernel_avg_ms": kavg_s * 1e3,
             "algorithmic_bytes_per_spectrum": abytes,
             "note": "the path is FP64-VALU bound (SURVEY.md 8d); see roofline_fp64",
