@@ -432,6 +432,16 @@ def test_errors_are_reported_not_swallowed(torch_mod):
     cfg["other"]["PhysParams"]["norm"] = 1
     with pytest.raises(_lib.TsffError, match="norm"):
         Engine(cfg, sa)
+    # the engine mirrors the Z' table about xi = 0 when LDS is short: a table that is not even / odd is refused
+    from tsadar_amd import engine as eng_mod
+
+    real = eng_mod.zprime_tables
+    try:
+        eng_mod.zprime_tables = lambda xi2: (real(xi2)[0] + 1e-3 * np.arange(xi2.size), real(xi2)[1])
+        with pytest.raises(_lib.TsffError, match="not even"):
+            Engine(decks.deck_fit(), sa)
+    finally:
+        eng_mod.zprime_tables = real
     cfg = decks.deck_fit()
     cfg["other"]["extraoptions"]["spectype"] = "bogus"
     from tsadar_amd.diagnostic import ThomsonScatteringDiagnostic
