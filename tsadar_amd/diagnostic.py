@@ -54,7 +54,7 @@ class ThomsonScatteringDiagnostic:
         lamI = np.tile(eng.lamAxisI[None, :], (B, 1))
         return E.cpu().numpy(), I.cpu().numpy(), lamE, lamI
 
-    def _angular(self, eng: Engine, ts_params: ThomsonParams, batch: Dict):
+    def _angular(self, eng: Engine, ts_params: ThomsonParams, batch: Dict, to_host: bool = True):
         """spectype "angular_full": one plasma condition -> the ARTS image ThryE [rows, n_lam]
         (FitModel.electron_spectrum matmul branch, add_ATS_IRF, reduce_ATS_to_resunit).  The ion feature is not
         measured by ARTS: ThryI = 0 + noise_i like the reference's modlI = 0."""
@@ -91,11 +91,13 @@ class ThomsonScatteringDiagnostic:
         p = phys[0]
         rows = eng._ats_shape[0]
         e_amps = np.broadcast_to(np.asarray(batch["e_amps"], dtype=np.float64).reshape(-1, 1), (rows, 1))
-        E = eng.ats_spectrum(P[0], e_amps, p[L.P_LAM], p[L.P_AMP1], p[L.P_AMP2]).cpu().numpy()
-        E = E + np.asarray(batch["noise_e"])
+        E_dev = eng.ats_spectrum(P[0], e_amps, p[L.P_LAM], p[L.P_AMP1], p[L.P_AMP2])
         lamE = np.mean(wavelength_axis_nm(cfg["other"]["lamrangE"], eng.npts).reshape(-1, lam_step), axis=1)
-        # what the adjoint (LossFunction._vg_angular) needs again: the device-resident P, the table and the parameters
-        self._angular_ctx = dict(P=P, phys=phys, fe2=fe2, fe1=fe1, e_amps=e_amps)
+        # what the adjoint (LossFunction._vg_angular) needs again: the device-resident P and image, the table, the parameters
+        self._angular_ctx = dict(P=P, phys=phys, fe2=fe2, fe1=fe1, e_amps=e_amps, E_dev=E_dev, lamE=lamE)
+        if not to_host:   # (the fit loop keeps the image on the device: the loss and its seed are evaluated there)
+            return None, None, lamE, []
+        E = E_dev.cpu().numpy() + np.asarray(batch["noise_e"])
         return E, 0 + np.asarray(batch["noise_i"]), lamE, []
 
     def spectrum_breakdown(self, ts_params, batch):

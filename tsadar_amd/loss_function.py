@@ -138,6 +138,43 @@ class LossFunction:
             derr = 1.0 - d / E
         return e_error, E, derr * wcol[None, :]
 
+    def _angular_value_device(self, eng, ts_params: ThomsonParams, batch, want_E: bool):
+        """_angular_value(want_bar=True) with the image, the data, the masks and the loss seed on the device (a handful of
+        element-wise torch operations on [rows, n_lam]; one scalar comes back): -> (value, ThryE or None, Ebar device)."""
+        torch = eng.torch
+        self.ts_diag._angular(eng, ts_params, batch, to_host=False)
+        ctx = self.ts_diag._angular_ctx
+        key = id(batch["e_data"])
+        if getattr(self, "_ang_dev_key", None) != key:
+            lamE = ctx["lamE"]
+            ext, r = self.cfg["other"]["extraoptions"], self.cfg["data"]["fit_rng"]
+            rows = ctx["E_dev"].shape[0]
+            wcol = np.zeros(lamE.size)
+            nterm = 0
+            for on, lo, hi in ((ext["fit_EPWb"], r["blue_min"], r["blue_max"]), (ext["fit_EPWr"], r["red_min"], r["red_max"])):
+                if on:
+                    m = (lamE > lo) & (lamE < hi)
+                    wcol[m] += 1.0 / (rows * max(int(m.sum()), 1))
+                    nterm += 1
+            if nterm == 2:
+                wcol *= 0.5
+            self._ang_dev = dict(d=eng.dev(np.ascontiguousarray(batch["e_data"], dtype=np.float64)), wcol=eng.dev(wcol)[None, :],
+                                 noise=eng.dev(np.array(np.atleast_1d(np.asarray(batch["noise_e"], dtype=np.float64)))))
+            self._ang_dev_key = key
+        dv = self._ang_dev
+        Et = ctx["E_dev"] + dv["noise"]
+        d, un, method = dv["d"], self.e_norm**2, self.cfg["optimizer"]["loss_method"]
+        if method == "l1":
+            err, derr = (d - Et).abs() / un, -torch.sign(d - Et) / un
+        elif method == "l2":
+            err, derr = (d - Et) ** 2 / un, -2.0 * (d - Et) / un
+        elif method == "log-cosh":
+            err, derr = torch.log(torch.cosh(d - Et)), -torch.tanh(d - Et)
+        else:
+            err, derr = Et - d * torch.log(Et), 1.0 - d / Et
+        value = float((err * dv["wcol"]).sum())
+        return value, (Et.cpu().numpy() if want_E else None), derr * dv["wcol"]
+
     def _vg_angular(self, diff_weights, static_weights, batch):
         """Value and gradient of the angular model by the hand-written adjoint -- loss seed -> tsff_ats_adjoint ->
         tsff_form_factor_2d_grad (2-D distribution functions: one rotated projection of the table per (wavelength, angle)
@@ -167,8 +204,9 @@ class LossFunction:
     def _vg_angular_adjoint(self, ts_params: ThomsonParams, diff_weights, batch):
         from . import distribution as Dist
 
-        value, E, Ebar = self._angular_value(ts_params, batch, want_bar=True)
         eng = self.ts_diag.engine(ts_params.activate)
+        want_E = self.cfg["optimizer"]["method"] != "l-bfgs-b"   # (the optax branch returns the image as aux)
+        value, E, Ebar = self._angular_value_device(eng, ts_params, batch, want_E)
         ctx = self.ts_diag._angular_ctx
         phys, P = ctx["phys"], ctx["P"]
         p = phys[0]
