@@ -179,6 +179,20 @@ def test_spherical_harmonics_generator():
     dc2["params"]["flm_type"] = "arbitrary"
     f2 = D.SphericalHarmonics(dc2)()
     np.testing.assert_allclose(f2, f2[::-1, ::-1], rtol=1e-12)           # zero-initialised harmonics: isotropic
+    # vector-Jacobian product of the generator (what LossFunction contracts the GPU's table adjoint with): the analytic chain
+    # of the free radial functions against central differences of the generator, at non-trivial parameter values
+    dc3 = copy.deepcopy(dc2)
+    dc3["nvx"], dc3["params"]["nvr"], dc3["params"]["init_m"] = 64, 32, 2.6
+    sh3 = D.SphericalHarmonics(dc3)
+    rng = np.random.default_rng(0)
+    th = sh3.get_params()
+    th[:-1] = rng.normal(0.0, 0.6, th.size - 1)
+    sh3.set_params(th)
+    fbar = rng.standard_normal((64, 64))
+    ga, gfd = sh3.vjp(fbar), sh3._vjp_fd(fbar)
+    assert ga.shape == (2 * 2 * 32 + 1,) and np.max(np.abs(ga - gfd)) < 1e-7 * np.max(np.abs(gfd))
+    np.testing.assert_array_equal(sh3.get_params(), th)                  # the generator is left untouched
+    assert np.max(np.abs(sh.vjp(fbar.repeat(2, 0).repeat(2, 1)) - sh._vjp_fd(fbar.repeat(2, 0).repeat(2, 1)))) == 0.0  # Mora-Yahi: FD
     dc2["params"]["flm_type"] = "nn"
     with pytest.raises(NotImplementedError):
         D.SphericalHarmonics(dc2)

@@ -183,9 +183,58 @@ class SphericalHarmonics:
         self.normed_m = float(vec[o])
 
     def vjp(self, fe_bar: np.ndarray, step: float = 1e-6) -> np.ndarray:
-        """d loss / d f_e[nvx, nvx] -> d loss / d get_params(): the generator is a cheap host function of a few
-        parameters, its Jacobian is taken by central differences (2 evaluations per parameter) and contracted with the
-        table adjoint that the GPU delivers."""
+        """d loss / d f_e[nvx, nvx] -> d loss / d get_params().  Free radial functions ("arbitrary": 2 nvr values per
+        harmonic) are chained analytically -- normalisation, floor, radial interpolation (transposed), 10^mag * sign,
+        sigmoid / tanh, smoothing (transposed) --; the super-Gaussian order of f00 and the Mora-Yahi gradient lengths (one
+        scalar each) by central differences of the generator."""
+        if self.flm_type != "arbitrary":
+            return self._vjp_fd(fe_bar, step)
+        theta = self.get_params()
+        out = np.zeros_like(theta)
+        f00 = self.get_f00()
+        nvr = self.vr.size
+        # forward pieces
+        rad, aux = {}, {}
+        w = np.hanning(nvr // 4)
+        w = w / w.sum()
+        M = np.stack([np.convolve(e, w, mode="same") for e in np.eye(nvr)], axis=1)   # sm(a) = M @ a
+        f = np.interp(self.vr_vxvy, self.vr, f00, right=1e-16)
+        for key in sorted(self.flm):
+            prm = self.flm[key]
+            v, u = M @ prm["flm_sign"], M @ prm["flm_mag"]
+            sg = 1.0 / (1.0 + np.exp(-u))
+            p10, th = 10.0 ** (-10.0 * sg), np.tanh(v)
+            rad[key], aux[key] = p10 * th, (p10, th, sg)
+            f = f + np.interp(self.vr_vxvy, self.vr, rad[key], right=1e-32) * real_sph_harm(key[0], key[1], self.phi, self.th)
+        live = f > 1e-32
+        fc = np.maximum(f, 1e-32)
+        tot, c = np.sum(fc), 1.0 / (self.vx[1] - self.vx[0]) ** 2
+        f_bar = c * (fe_bar / tot - np.sum(fe_bar * fc) / tot**2) * live
+        # transposed linear interpolation onto the radial nodes (np.interp: left of the first node = its value, right of
+        # the last = the constant `right`)
+        q = self.vr_vxvy.ravel()
+        i = np.clip(np.searchsorted(self.vr, q, side="right") - 1, 0, nvr - 2)
+        t = np.clip((q - self.vr[i]) / (self.vr[i + 1] - self.vr[i]), 0.0, 1.0)
+        inside = q <= self.vr[-1]
+        o = 0
+        for key in sorted(self.flm):
+            g = (f_bar * real_sph_harm(key[0], key[1], self.phi, self.th)).ravel() * inside
+            r_bar = np.bincount(i, weights=g * (1.0 - t), minlength=nvr) + np.bincount(i + 1, weights=g * t, minlength=nvr)
+            p10, th, sg = aux[key]
+            out[o : o + nvr] = M.T @ (r_bar * p10 * (1.0 - th**2))                                       # flm_sign
+            out[o + nvr : o + 2 * nvr] = M.T @ (r_bar * rad[key] * np.log(10.0) * (-10.0) * sg * (1.0 - sg))   # flm_mag
+            o += 2 * nvr
+        # the order of f00: one scalar, central difference
+        vals = []
+        for sgn in (+1.0, -1.0):
+            self.normed_m = theta[-1] + sgn * step
+            vals.append(self())
+        self.normed_m = theta[-1]
+        out[-1] = np.sum(fe_bar * (vals[0] - vals[1])) / (2.0 * step)
+        return out
+
+    def _vjp_fd(self, fe_bar: np.ndarray, step: float = 1e-6) -> np.ndarray:
+        """Central differences of the generator, 2 evaluations per parameter (cross-check of vjp; Mora-Yahi)."""
         theta = self.get_params()
         out = np.zeros_like(theta)
         for i in range(theta.size):
