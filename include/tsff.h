@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TSFF_ABI_VERSION 5
+#define TSFF_ABI_VERSION 6
 
 /* ---- parameter slots of one lineout: params[b][TSFF_NP(n_ion)] (normalised leaves of the
  * reference's ThomsonParams pytree, core/modules/ts_params.py:49-60,395-420,253-262) ---------- */
@@ -196,6 +196,14 @@ int tsff_form_factor_2d_range(tsff_handle *h, int32_t feature, const double *phy
                               int32_t shared_fe, double ud_angle_deg, double va_angle_deg, int32_t B,
                               int64_t point_begin, int64_t point_end, double *P);
 
+/* tsff_form_factor_2d_range for ONE shared table (nv <= 256) that also keeps, in the handle, the projection record of
+ * every point of the range (the projected distribution and the derivative sums of its rotation: proj2d_doubles(nv)
+ * doubles per point): the adjoint that follows in a fit step (tsff_form_factor_2d_grad with use_saved != 0, same
+ * feature / table size / point range, same phys and fe2d) then does no sampling of its own. */
+int tsff_form_factor_2d_save(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
+                             double ud_angle_deg, double va_angle_deg, int32_t B, int64_t point_begin,
+                             int64_t point_end, double *P);
+
 /* Adjoint of tsff_form_factor_2d for ONE shared table (the 2-D path is never batched in the reference): given
  * Pbar = d loss / d P (device, [B][G][npts][n_angles]) ->
  *   grad_phys [B][NP] (device): d loss / d PHYSICAL parameters (Te, ne, lam, ne_gradient, Te_gradient, ud, Va, Ti, Z;
@@ -204,10 +212,12 @@ int tsff_form_factor_2d_range(tsff_handle *h, int32_t feature, const double *phy
  *     weights scattered by LDS atomics, ghost cells folded back).
  * [point_begin, point_end) (point_end < 0: to the end): the contributions of that slice of the flat point list only --
  * both adjoints are sums over points, so the ranks of a node each take a slice and all-reduce the two outputs.
+ * use_saved != 0: the projections come from the records of the preceding tsff_form_factor_2d_save (see there).
  * Replaces what JAX reverse mode gives the reference for angular fits (inverse/loops.py:167-275). */
 int tsff_form_factor_2d_grad(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
                              double ud_angle_deg, double va_angle_deg, int32_t B, int64_t point_begin,
-                             int64_t point_end, const double *Pbar, double *grad_phys, double *grad_fe2d);
+                             int64_t point_end, int32_t use_saved, const double *Pbar, double *grad_phys,
+                             double *grad_fe2d);
 
 /* Angular (ARTS) instrument chain for one image P[G][npts][n_angles] (device; from tsff_form_factor_2d or, for a 1-D
  * distribution function, tsff_form_factor): FitModel.electron_spectrum "angular_full" branch

@@ -1272,6 +1272,17 @@ def test_form_factor_2d_grad_finite_differences(torch_mod, nv, n_ion, G):
         # without the table adjoint the parameter gradient is the same
         gp2, none = eng.form_factor_2d_grad(feature, X, fe2, Pbar, ud_ang, va_ang, want_table=False)
         assert none is None and np.allclose(gp2.cpu().numpy(), gp, rtol=1e-12, atol=0)
+        # fit-loop form: the forward keeps the projection records (tsff_form_factor_2d_save), the adjoint does no sampling
+        if nv <= 256:
+            P1 = eng.form_factor_2d(feature, X, fe2, ud_ang, va_ang, save=True)
+            assert torch.allclose(P1, P0, rtol=1e-13, atol=0)
+            gp3, gf3 = eng.form_factor_2d_grad(feature, X, fe2, Pbar, ud_ang, va_ang, use_saved=True)
+            assert np.max(np.abs(gp3.cpu().numpy() - gp)) < 1e-11 * np.max(np.abs(gp))
+            assert np.max(np.abs(gf3.cpu().numpy() - gf)) < 1e-11 * np.max(np.abs(gf))
+            eng.form_factor_2d(feature, X, fe2, ud_ang, va_ang)   # a plain forward invalidates the records
+            with pytest.raises(L.TsffError, match="use_saved"):
+                eng._saved_2d = True
+                eng.form_factor_2d_grad(feature, X, fe2, Pbar, ud_ang, va_ang, use_saved=True)
 
 
 @pytest.mark.parametrize("fe_type", ["arbitrary", "sphericalharmonic"])

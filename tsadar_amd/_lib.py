@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsff.so")
 LIB_PATH = os.environ.get("TSFF_LIBRARY", LIB_PATH)  # A/B experiments: another in-tree build of the same ABI
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_ION = 4
 NBINS = 1024
 NXI1 = 1024
@@ -112,7 +112,8 @@ _SIGNATURES = {
     "tsff_form_factor_2d": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, _vp]),
     "tsff_form_factor_2d_range": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32,
                                             C.c_int64, C.c_int64, _vp]),
-    "tsff_form_factor_2d_grad": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_int64, _vp, _vp, _vp]),
+    "tsff_form_factor_2d_grad": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp]),
+    "tsff_form_factor_2d_save": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_int64, _vp]),
     "tsff_ats_setup": (C.c_int, [_vp, C.POINTER(TsffAtsConfig)]),
     "tsff_ats_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "tsff_ats_adjoint": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, c_double_p]),

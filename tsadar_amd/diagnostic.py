@@ -82,9 +82,9 @@ class ThomsonScatteringDiagnostic:
             if self.dist is not None and self.dist[0] > 1:
                 from . import distributed as D
 
-                P = D.form_factor_2d_sharded(eng, 0, phys, fe2, gen["ud"]["angle"], gen["Va"]["angle"], *self.dist)
-            else:
-                P = eng.form_factor_2d(0, phys, fe2, gen["ud"]["angle"], gen["Va"]["angle"])
+                P = D.form_factor_2d_sharded(eng, 0, phys, fe2, gen["ud"]["angle"], gen["Va"]["angle"], *self.dist, save=not to_host)
+            else:   # (fit loop, to_host False: keep the projections for the adjoint that follows)
+                P = eng.form_factor_2d(0, phys, fe2, gen["ud"]["angle"], gen["Va"]["angle"], save=not to_host)
         else:
             fe1 = np.ascontiguousarray(np.asarray(ts_params()["electron"]["fe"], dtype=np.float64).reshape(1, -1))
             P = eng.form_factor(0, phys, fe1)

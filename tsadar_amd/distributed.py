@@ -101,14 +101,14 @@ def point_range(n_points: int, world: int, rank: int):
     return lo, min(lo + chunk, n_points), chunk
 
 
-def form_factor_2d_sharded(engine, feature, phys, fe2d, ud_angle, va_angle, world: int, rank: int, group=None):
+def form_factor_2d_sharded(engine, feature, phys, fe2d, ud_angle, va_angle, world: int, rank: int, group=None, save=False):
     """FormFactor.calc_in_2D over the ranks of a node: f_e and parameters replicated, each rank evaluates its slice of
     the point list (tsff_form_factor_2d_range), one all-gather of equal (padded) chunks assembles P on every rank.
     No reduction is involved; the result is bit-identical to the single-rank one."""
     import torch
 
     if world == 1:
-        return engine.form_factor_2d(feature, phys, fe2d, ud_angle, va_angle)
+        return engine.form_factor_2d(feature, phys, fe2d, ud_angle, va_angle, save=save)
     import torch.distributed as dist
 
     B = np.asarray(phys).reshape(-1, engine.NP).shape[0] if not hasattr(phys, "shape") else int(phys.reshape(-1, engine.NP).shape[0])
@@ -117,26 +117,27 @@ def form_factor_2d_sharded(engine, feature, phys, fe2d, ud_angle, va_angle, worl
     lo, hi, chunk = point_range(n, world, rank)
     full = torch.zeros(chunk * world, dtype=torch.float64, device=engine.device)
     view = full[:n].view(shape)
-    engine.form_factor_2d(feature, phys, fe2d, ud_angle, va_angle, point_range=(lo, hi), out=view)
+    engine.form_factor_2d(feature, phys, fe2d, ud_angle, va_angle, point_range=(lo, hi), out=view, save=save)
     mine = full[rank * chunk : (rank + 1) * chunk].clone()
     dist.all_gather_into_tensor(full, mine, group=group)
     return full[:n].view(shape)
 
 
 def form_factor_2d_grad_sharded(engine, feature, phys, fe2d, Pbar, ud_angle, va_angle, world: int, rank: int, group=None,
-                                want_table=True):
+                                want_table=True, use_saved=False):
     """Adjoint of the 2-D path over the ranks of a node: every rank holds Pbar, the table and the parameters, reverses its
     slice of the point list (tsff_form_factor_2d_grad with a point range) and ONE all-reduce sums the packed
     [grad_phys | grad_fe2d] -- both are sums over points.  -> (grad_phys [B, NP], grad_fe2d [nv, nv] or None)."""
     import torch
 
     if world == 1:
-        return engine.form_factor_2d_grad(feature, phys, fe2d, Pbar, ud_angle, va_angle, want_table=want_table)
+        return engine.form_factor_2d_grad(feature, phys, fe2d, Pbar, ud_angle, va_angle, want_table=want_table, use_saved=use_saved)
     import torch.distributed as dist
 
     n = int(Pbar.numel()) if hasattr(Pbar, "numel") else int(np.asarray(Pbar).size)
     lo, hi, _ = point_range(n, world, rank)
-    gp, gf = engine.form_factor_2d_grad(feature, phys, fe2d, Pbar, ud_angle, va_angle, want_table=want_table, point_range=(lo, hi))
+    gp, gf = engine.form_factor_2d_grad(feature, phys, fe2d, Pbar, ud_angle, va_angle, want_table=want_table, point_range=(lo, hi),
+                                        use_saved=use_saved)
     packed = torch.cat([gp.reshape(-1), gf.reshape(-1)]) if gf is not None else gp.reshape(-1).clone()
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     gp_out = packed[: gp.numel()].view_as(gp)

@@ -347,7 +347,7 @@ class Engine:
                                                                  self._ptr(Pb), self._ptr(gp), self._ptr(gf)))
         return gp, gf
 
-    def form_factor_2d(self, feature, phys, fe2d, ud_angle=0.0, va_angle=0.0, point_range=None, out=None):
+    def form_factor_2d(self, feature, phys, fe2d, ud_angle=0.0, va_angle=0.0, point_range=None, out=None, save=False):
         """FormFactor.calc_in_2D: phys [B, NP] PHYSICAL parameters, fe2d [nv, nv] (shared) or [B, nv, nv]
         -> P [B, G, npts, n_angles].  ``point_range = (begin, end)`` evaluates that slice of the flat point list only
         (the rest of ``out`` / a zero-filled result is untouched): the sharding unit of the multi-GPU path."""
@@ -365,12 +365,19 @@ class Engine:
             P = (torch.zeros if point_range is not None else torch.empty)((B, G, self.npts, NA), dtype=torch.float64, device=self.device)
         lo, hi = point_range if point_range is not None else (0, -1)
         self._sync_stream()
-        rc = self.lib.tsff_form_factor_2d_range(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, int(shared),
-                                                float(ud_angle), float(va_angle), B, int(lo), int(hi), self._ptr(P))
+        if save and shared and nv <= 256:   # keep the projection records for form_factor_2d_grad(use_saved=True)
+            rc = self.lib.tsff_form_factor_2d_save(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, float(ud_angle),
+                                                   float(va_angle), B, int(lo), int(hi), self._ptr(P))
+            self._saved_2d = True
+        else:
+            self._saved_2d = False
+            rc = self.lib.tsff_form_factor_2d_range(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, int(shared),
+                                                    float(ud_angle), float(va_angle), B, int(lo), int(hi), self._ptr(P))
         L.check(self.lib, self.h, rc)
         return P
 
-    def form_factor_2d_grad(self, feature, phys, fe2d, Pbar, ud_angle=0.0, va_angle=0.0, want_table=True, point_range=None):
+    def form_factor_2d_grad(self, feature, phys, fe2d, Pbar, ud_angle=0.0, va_angle=0.0, want_table=True, point_range=None,
+                            use_saved=False):
         """Adjoint of form_factor_2d (one shared table): Pbar [B, G, npts, n_angles] ->
         (grad_phys [B, NP], grad_fe2d [nv, nv] or None) as device tensors.  ``point_range = (begin, end)``: the
         contributions of that slice of the flat point list only (to be summed over the ranks of a node)."""
@@ -385,7 +392,8 @@ class Engine:
         self._sync_stream()
         lo, hi = point_range if point_range is not None else (0, -1)
         rc = self.lib.tsff_form_factor_2d_grad(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, float(ud_angle),
-                                               float(va_angle), B, int(lo), int(hi), self._ptr(Pb), self._ptr(gp), self._ptr(gf))
+                                               float(va_angle), B, int(lo), int(hi), int(bool(use_saved) and getattr(self, "_saved_2d", False)),
+                                               self._ptr(Pb), self._ptr(gp), self._ptr(gf))
         L.check(self.lib, self.h, rc)
         return gp, gf
 

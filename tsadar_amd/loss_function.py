@@ -218,10 +218,10 @@ class LossFunction:
             want_table = any(s in (tree.GEN2D_SLOT, tree.FVAL2D_SLOT) for _, s in diff_weights.slots)
             if self.ts_diag.dist is not None and self.ts_diag.dist[0] > 1:
                 gp, gfe = D.form_factor_2d_grad_sharded(eng, 0, phys, ctx["fe2"], Pbar.reshape(P.shape), gen["ud"]["angle"],
-                                                        gen["Va"]["angle"], *self.ts_diag.dist, want_table=want_table)
+                                                        gen["Va"]["angle"], *self.ts_diag.dist, want_table=want_table, use_saved=True)
             else:
                 gp, gfe = eng.form_factor_2d_grad(0, phys, ctx["fe2"], Pbar.reshape(P.shape), gen["ud"]["angle"],
-                                                  gen["Va"]["angle"], want_table=want_table)
+                                                  gen["Va"]["angle"], want_table=want_table, use_saved=True)
         else:
             want_fe = any(s in (tree.FVAL_SLOT, L.P_M) for _, s in diff_weights.slots)
             gp, gfe = eng.form_factor_grad(0, phys, ctx["fe1"], Pbar.reshape(P.shape), want_fe=want_fe)
