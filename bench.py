@@ -106,13 +106,27 @@ def main():
     from tsadar_amd import distributed as D
     from tsadar_amd.engine import Engine
 
-    world, rank, local = D.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
+    # RCCL prints a five-line banner (version, hostname, library path) on the process's STDOUT when its first communicator
+    # is created: keep stdout for the one JSON line by pointing fd 1 at stderr until the communicator exists
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        world, rank, local = D.init_from_env()
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        if world > 1:
+            import torch.distributed as dist
+
+            warm = torch.zeros(1, dtype=torch.float64, device=dev)
+            dist.all_reduce(warm)   # (creates the communicator)
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
 
     B = args.batch
     active = ("Te", "ne", "m", "amp1", "amp2", "lam") if args.dlm else S.ACTIVE
