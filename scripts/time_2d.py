@@ -37,3 +37,12 @@ for nv, na in ((128, 241), (256, 512)):
         da = time.perf_counter() - t0
         print(f"   adjoint (table adjoint {want_table}): {da*1e3:.1f} ms = {da/dt:.2f} forwards, finite "
               f"{bool(torch.isfinite(gp).all()) and (gf is None or bool(torch.isfinite(gf).all()))}", flush=True)
+    # the fit-loop form: the forward keeps the projection records, the adjoint does no sampling
+    def _t(fn, n=2):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+    ds = _t(lambda: eng.form_factor_2d(0, tp.physical_matrix(), fd, 10.0, 20.0, save=True))
+    da = _t(lambda: eng.form_factor_2d_grad(0, tp.physical_matrix(), fd, Pbar, 10.0, 20.0, want_table=False, use_saved=True))
+    dt_ = _t(lambda: eng.form_factor_2d_grad(0, tp.physical_matrix(), fd, Pbar, 10.0, 20.0, want_table=True, use_saved=True))
+    print(f"   fit-loop form: forward + records {ds:.1f} ms, adjoint from records {da:.1f} ms (parameters), {dt_:.1f} ms (with table adjoint)", flush=True)
