@@ -1044,7 +1044,8 @@ def test_angular_vg_loss_finite_difference(torch_mod):
     v2, g2 = loss_fn.vg_loss(x0, static, batch)
     loss_fn.force_fd = False
     # (step 1e-5 of the fallback straddles kinks of the table lookups: it is the less accurate of the two)
-    assert v2 == val and np.max(np.abs(g2 - g)) < 1e-2 * np.max(np.abs(g)), (g2, g)
+    # (value: host NumPy sums on the fallback path, device sums on the adjoint path)
+    assert abs(v2 - val) < 1e-13 * abs(val) and np.max(np.abs(g2 - g)) < 1e-2 * np.max(np.abs(g)), (g2, g)
     # the reference's round trip on two parameters (Te, ne; the DLM order held at its true value)
     cfg["parameters"]["electron"]["fe"]["active"] = False
     truth2 = orc.init_normed_params(cfg["parameters"], 1, True)
@@ -1363,7 +1364,7 @@ def test_angular_2d_vg_loss_adjoint(torch_mod, fe_type):
         loss_fn.force_fd = True
         v2, g2 = loss_fn.vg_loss(x0, static, batch)
         loss_fn.force_fd = False
-        assert v2 == val
+        assert abs(v2 - val) < 1e-13 * abs(val)
         lam_i = names.index(("general", "lam"))
         keep = np.ones(x0.size, bool)
         keep[lam_i if lam_i < names.index(("electron", "fe")) else lam_i + 2] = False
