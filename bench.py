@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--free-form", action="store_true",
                     help="variant: explicit per-lineout f_e tables with the gradient w.r.t. f_e itself (Arbitrary1V-style "
                          "free-form distribution, nvx more unknowns per lineout; not the headline metric)")
-    ap.add_argument("--plan", type=int, default=0, help="launch plan (experiments): 0 automatic, 1 never interleave the features")
+    ap.add_argument("--plan", type=int, default=0, help="launch plan bit mask (experiments): 0 automatic, 1 never interleave the features, 2 two-sweep kernel instead of the one-sweep one")
     args = ap.parse_args()
     variant = args.dlm or args.free_form
 

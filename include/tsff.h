@@ -150,9 +150,11 @@ int tsff_set_stream(tsff_handle *h, void *hip_stream);
 /* options.  TSFF_OPT_DENOM_MODE: denominators of the l1/l2 functionals in tsff_loss_grad -- 0 (default):
  * constants folded into `weights` (LossFunction.__loss__, loss_function.py:364-373); 2: |data| + 1e-10 per sample
  * (LossFunction._loss_for_hess_fn_, loss_function.py:173-188, the loss whose Hessian gives the fit uncertainties).
- * TSFF_OPT_LAUNCH_PLAN: 0 (default) automatic -- with two loaded features one launch of 2B 256-thread workgroups, one
- * per (lineout, feature), when two of them fit a CU; 1: never interleave (both features in one 512-thread workgroup).
- * The spectra are identical either way; the gradient differs by the rounding of one addition. */
+ * TSFF_OPT_LAUNCH_PLAN: bit mask, 0 (default) automatic -- with two loaded features one launch of 2B 256-thread workgroups, one
+ * per (lineout, feature), when two of them fit a CU; tsff_loss_grad runs the one-sweep kernel (forward value and Jacobian rows
+ * of every wavelength sample in one pass over the points) where it applies: one gradient point, one point per pixel, n_ion <= 2,
+ * no gradient w.r.t. the tabulated f_e.  Bit 0: never interleave (both features in one 512-thread workgroup); bit 1: always the
+ * two-sweep kernel.  The spectra are identical either way; the gradient differs by rounding. */
 enum { TSFF_OPT_DENOM_MODE = 1, TSFF_OPT_LAUNCH_PLAN = 2 };
 int tsff_set_option(tsff_handle *h, int32_t key, int32_t value);
 /* make sure the workspace holds B lineouts (calls grow it lazily; not inside graph capture) */

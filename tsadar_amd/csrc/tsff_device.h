@@ -190,11 +190,12 @@ __device__ __forceinline__ void fe_add_h(FeAcc& a, const Tables& T, double x, do
 
 // jnp.interp(xie, xi2, W): clamps to the end values outside the table (form_factor.py:270)
 __device__ __forceinline__ void w_lookup(const double* W, double xe, double& w, double& dw) {
+#pragma clang fp contract(off)   // (every rounding that reaches a spectrum is written out: the same bits from every kernel)
   const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
   double u = (xe - kXi2_0) * kXi2_ih;
   int i = (int)u;
   i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
-  double t = (xe - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
+  double t = (xe - __builtin_fma((double)i, kXi2_h, kXi2_0)) * kXi2_ih;
   const double a = W[i], b = W[i + 1];
 #if TSFF_BRANCHFREE
   // straight-line form: one scheduling region per point, so the LDS reads can be hoisted over the arithmetic
@@ -219,24 +220,17 @@ __device__ __forceinline__ void hermite_coeffs(double2 a, double2 b, double dv, 
 
 // the same lookup as hermite_lookup() below from the per-interval coefficient table
 __device__ __forceinline__ void hermite_lookup_c(const Tables& T, double x, double& H, double& dH) {
+#pragma clang fp contract(off)
   const double u = (x - T.vx0) * T.idv;
   int i = (int)u;
   i = i < 0 ? 0 : (i > T.nvx - 2 ? T.nvx - 2 : i);
-  const double t = (x - (T.vx0 + i * T.dv)) * T.idv;
+  const double t = (x - __builtin_fma((double)i, T.dv, T.vx0)) * T.idv;
   const double2 c01 = T.hc[2 * i], c23 = T.hc[2 * i + 1];
-#if TSFF_BRANCHFREE
   const bool out = x < T.vx0 || x > T.vxlast;
-  const double Hi = c01.x + t * (c01.y + t * (c23.x + t * c23.y));
-  const double dHi = (c01.y + t * (2.0 * c23.x + 3.0 * t * c23.y)) * T.idv;
+  const double Hi = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, c23.y, c23.x), c01.y), c01.x);
+  const double dHi = __builtin_fma(t, __builtin_fma(3.0 * t, c23.y, 2.0 * c23.x), c01.y) * T.idv;
   H = out ? -50.0 : Hi;
   dH = out ? 0.0 : dHi;
-#else
-  if (x < T.vx0 || x > T.vxlast) { H = -50.0; dH = 0.0; }
-  else {
-    H = c01.x + t * (c01.y + t * (c23.x + t * c23.y));
-    dH = (c01.y + t * (2.0 * c23.x + 3.0 * t * c23.y)) * T.idv;
-  }
-#endif
 }
 
 // interpax.interp1d(x, vx, ln fe, method="cubic", extrap=[-50,-50])  (form_factor.py:256,263)
@@ -397,7 +391,7 @@ __device__ __forceinline__ double fexp(double x) {
   return exp(x);
 #endif
   x = fmax(x, -800.0);
-  const double n = __builtin_rint(x * 1.4426950408889634074);
+  const double n = __builtin_rint(x * 1.4426950408889634074);   // (not contractible: rint takes the product)
   double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
   r = __builtin_fma(n, -1.90821492927058770002e-10, r);
 #if TSFF_FEXP == 1
@@ -455,20 +449,21 @@ struct Base {  // quantities needed at point j AND as the right neighbour of poi
 // k_s = sqrt(w_s^2 - wpe^2)/c (form_factor.py:218; angle independent)
 __device__ __forceinline__ double ks_eval(double ws, double wpe2) {
   double s, is;
-  fsqrt2(ws * ws - wpe2, s, is);
+  fsqrt2(__builtin_fma(ws, ws, -wpe2), s, is);
   return s * (1.0 / kC);
 }
 
 template <int NI>
 __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const LineS<NI>& L, const Tables& T,
                                           Base& b) {
+#pragma clang fp contract(off)
   b.ks = ks;
-  b.k2 = __builtin_fma(ks, ks - 2.0 * L.kL * ct, L.kL * L.kL);   // :220  k_s^2 + k_L^2 - 2 k_s k_L cos(theta); the two
-                                                                  // uniform products are hoisted out of the strip loop
+  const double c1 = (2.0 * L.kL) * ct, c0 = L.kL * L.kL;   // wavefront-uniform: hoisted out of the strip loops
+  b.k2 = __builtin_fma(ks, ks - c1, c0);                   // :220  k_s^2 + k_L^2 - 2 k_s k_L cos(theta)
   double k;
   fsqrt2(b.k2, k, b.ik);
-  b.wd = (ws - L.wL) - k * L.Vd;                           // :216, 222-223
-  b.xe = (b.wd * b.ik - L.Ud) * L.ivTe;                    // :253
+  b.wd = __builtin_fma(-k, L.Vd, ws - L.wL);               // :216, 222-223
+  b.xe = __builtin_fma(b.wd, b.ik, -L.Ud) * L.ivTe;        // :253
   double H;
   hermite_lookup_c(T, b.xe, H, b.dH);
   b.F = fexp(H);                                           // :256
@@ -487,28 +482,29 @@ constexpr int kNZh = kNXi2 / 2 + 1;
 template <bool ZH = true>
 __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& zr, double& zi, double& dzr,
                                           double& dzi, double& gs) {
-  gs = fexp(-xi * xi) * kInvSqrt2Pi;
+#pragma clang fp contract(off)
+  gs = fexp(-(xi * xi)) * kInvSqrt2Pi;
   const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
   if (ZH) {
     const double ax = fabs(xi);
     int i = (int)(ax * kXi2_ih);
     i = i > kNZh - 2 ? kNZh - 2 : i;
-    const double t = (ax - i * kXi2_h) * kXi2_ih;
+    const double t = __builtin_fma(-(double)i, kXi2_h, ax) * kXi2_ih;
     const double2 a = zp[i], b = zp[i + 1];
     const double dr = b.x - a.x, di = b.y - a.y;
     // odd parts take the sign of xi: one AND and two XORs on the high words instead of compare + selects
     const int sx = __double2hiint(xi) & (int)0x80000000;
-    const double zia = a.y + t * di, dzra = dr * kXi2_ih;
-    zr = a.x + t * dr; dzi = di * kXi2_ih;
+    const double zia = __builtin_fma(t, di, a.y), dzra = dr * kXi2_ih;
+    zr = __builtin_fma(t, dr, a.x); dzi = di * kXi2_ih;
     zi = __hiloint2double(__double2hiint(zia) ^ sx, __double2loint(zia));
     dzr = __hiloint2double(__double2hiint(dzra) ^ sx, __double2loint(dzra));
   } else {
     int i = (int)((xi - kXi2_0) * kXi2_ih);
     i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
-    const double t = (xi - (kXi2_0 + i * kXi2_h)) * kXi2_ih;
+    const double t = (xi - __builtin_fma((double)i, kXi2_h, kXi2_0)) * kXi2_ih;
     const double2 a = zp[i], b = zp[i + 1];
     const double dr = b.x - a.x, di = b.y - a.y;
-    zr = a.x + t * dr; zi = a.y + t * di; dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
+    zr = __builtin_fma(t, dr, a.x); zi = __builtin_fma(t, di, a.y); dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
   }
   const bool out = xi < kXi2_0 || xi > xlast;
   // straight-line form (selects instead of branches: one scheduling region per point; wavefront-uniform shortcuts for the
@@ -518,37 +514,58 @@ __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& 
   zr = out ? i2 : zr; zi = out ? 0.0 : zi; dzr = out ? di2 : dzr; dzi = out ? 0.0 : dzi;
 }
 
-// P(lambda_j, theta_a) of one gradient point (form_factor.py:247-296)
+// P(lambda_j, theta_a) of one gradient point (form_factor.py:247-296): the forward algebra shared by every kernel that
+// evaluates a point (forward sweep, reverse sweep, one-sweep kernel).  The roundings that reach the spectrum are pinned by
+// explicit FMAs, so that a spectrum comes out bit-identical from tsff_forward and from tsff_loss_grad whatever kernel runs.
+template <int NI>
+struct PointF {
+  double ik2, ike2, pike, vph, cre, cim, gsum, Wl, dW, idx, D, cer, cei, opc, er, ei, ieps2, ce2, ci2, N, t1, S, dop;
+  double xi[NI], zr[NI], zi[NI], dzr[NI], dzi[NI], iki2[NI], gs[NI];
+};
+template <int NI, bool ZH>
+__device__ __forceinline__ void point_core(const Base& b, const Base& bn, bool has_next, const LineS<NI>& L, const Tables& T,
+                                           PointF<NI>& p) {
+#pragma clang fp contract(off)
+  p.ik2 = b.ik * b.ik;
+  p.ike2 = L.a_e * p.ik2;
+  p.pike = kPi * p.ike2;
+  p.vph = b.wd * b.ik;
+  double cre = 0.0, cim = 0.0, gsum = 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    p.xi[s] = p.vph * L.ixi[s];                              // :243
+    ion_terms<ZH>(T.zp, p.xi[s], p.zr[s], p.zi[s], p.dzr[s], p.dzi[s], p.gs[s]);
+    p.iki2[s] = L.a_i[s] * p.ik2;
+    const double hk = -0.5 * p.iki2[s];
+    cre = __builtin_fma(hk, p.zr[s], cre);                   // :249
+    cim = __builtin_fma(hk, p.zi[s], cim);
+    gsum = __builtin_fma(L.cs[s], p.gs[s], gsum);            // :277-280
+  }
+  p.cre = cre; p.cim = cim; p.gsum = gsum;
+  w_lookup(T.W, b.xe, p.Wl, p.dW);
+  p.idx = has_next ? frcp(bn.xe - b.xe) : 0.0;
+  p.D = has_next ? (bn.F - b.F) * p.idx : 0.0;               // :258-259
+  p.cer = -p.ike2 * p.Wl;                                    // :270-271
+  p.cei = p.pike * p.D;                                      // :261
+  p.opc = 1.0 + cre;
+  p.er = p.opc + p.cer; p.ei = p.cei + cim;                  // :274
+  const double eps2 = __builtin_fma(p.er, p.er, p.ei * p.ei);
+  p.ieps2 = frcp(eps2);
+  p.ce2 = __builtin_fma(p.cer, p.cer, p.cei * p.cei);
+  p.ci2 = __builtin_fma(p.opc, p.opc, cim * cim);
+  p.N = __builtin_fma(gsum, p.ce2, (p.ci2 * b.F) * L.ivTe);  // :282-288
+  p.t1 = b.ik * p.ieps2;
+  p.S = p.N * p.t1;
+  p.dop = __builtin_fma(b.wd, L.i2wL, 1.0);                  // :291
+}
 // point_forward_sd: S (1 + 2 w/w_L) -- everything but the factor pref ws^2, which k_spectrum applies once per angle
 // (pref) and once per wavelength sample (ws^2) instead of once per point
 template <int NI, bool ZH = true>
 __device__ __forceinline__ double point_forward_sd(const Base& b, const Base& bn, bool has_next, const LineS<NI>& L,
                                                    const Tables& T) {
-  const double ik2 = b.ik * b.ik;
-  const double ike2 = L.a_e * ik2;
-  const double vph = b.wd * b.ik;
-  double cre = 0.0, cim = 0.0, gsum = 0.0;
-#pragma unroll
-  for (int s = 0; s < NI; ++s) {
-    const double xi = vph * L.ixi[s];                      // :243
-    double zr, zi, dzr, dzi, gs;
-    ion_terms<ZH>(T.zp, xi, zr, zi, dzr, dzi, gs);
-    const double iki2 = L.a_i[s] * ik2;
-    cre -= 0.5 * iki2 * zr;                                // :249
-    cim -= 0.5 * iki2 * zi;
-    gsum += L.cs[s] * gs;                                  // :277-280
-  }
-  double Wl, dW;
-  w_lookup(T.W, b.xe, Wl, dW);
-  const double D = has_next ? (bn.F - b.F) * frcp(bn.xe - b.xe) : 0.0;  // :258-259
-  const double cer = -ike2 * Wl;                           // :270-271
-  const double cei = kPi * ike2 * D;                       // :261
-  const double er = 1.0 + cer + cre, ei = cei + cim;       // :274
-  const double eps2 = er * er + ei * ei;
-  const double ce2 = cer * cer + cei * cei;
-  const double ci2 = (1.0 + cre) * (1.0 + cre) + cim * cim;
-  const double S = (gsum * ce2 + ci2 * b.F * L.ivTe) * b.ik * frcp(eps2);  // :282-288
-  return S * (1.0 + b.wd * L.i2wL);                                        // :291
+  PointF<NI> p;
+  point_core<NI, ZH>(b, bn, has_next, L, T, p);
+  return p.S * p.dop;
 }
 template <int NI>
 __device__ __forceinline__ double point_forward(double ws, const Base& b, const Base& bn, bool has_next,
@@ -569,35 +586,13 @@ __device__ __forceinline__ void point_reverse(const Base& b, const Base& bn, boo
                                               const LineS<NI>& L, const Tables& T, double PQ,
                                               BaseAdj& ba, double& xen, double& Fn, LineS<NI>& LB, FeAcc& fa) {
   // ---- recompute forward ----
-  const double ik2 = b.ik * b.ik;
-  const double ike2 = L.a_e * ik2;
-  const double pike = kPi * ike2;
-  const double vph = b.wd * b.ik;
-  double cre = 0.0, cim = 0.0, gsum = 0.0;
-  double xi[NI], zr[NI], zi[NI], dzr[NI], dzi[NI], iki2[NI], gs[NI];
-#pragma unroll
-  for (int s = 0; s < NI; ++s) {
-    xi[s] = vph * L.ixi[s];
-    ion_terms<ZH>(T.zp, xi[s], zr[s], zi[s], dzr[s], dzi[s], gs[s]);
-    iki2[s] = L.a_i[s] * ik2;
-    cre -= 0.5 * iki2[s] * zr[s];
-    cim -= 0.5 * iki2[s] * zi[s];
-    gsum += L.cs[s] * gs[s];
-  }
-  double Wl, dW;
-  w_lookup(T.W, b.xe, Wl, dW);
-  const double idx = has_next ? frcp(bn.xe - b.xe) : 0.0;
-  const double D = has_next ? (bn.F - b.F) * idx : 0.0;
-  const double cer = -ike2 * Wl, cei = pike * D;
-  const double opc = 1.0 + cre;
-  const double er = opc + cer, ei = cei + cim;
-  const double eps2 = er * er + ei * ei, ieps2 = frcp(eps2);
-  const double ce2 = cer * cer + cei * cei;
-  const double ci2 = opc * opc + cim * cim;
-  const double N = gsum * ce2 + ci2 * b.F * L.ivTe;
-  const double t1 = b.ik * ieps2;
-  const double S = N * t1;
-  const double dop = 1.0 + b.wd * L.i2wL;
+  PointF<NI> pf;
+  point_core<NI, ZH>(b, bn, has_next, L, T, pf);
+  const double ik2 = pf.ik2, ike2 = pf.ike2, vph = pf.vph, gsum = pf.gsum, Wl = pf.Wl, dW = pf.dW, idx = pf.idx, D = pf.D;
+  const double cer = pf.cer, cei = pf.cei, opc = pf.opc, cim = pf.cim, er = pf.er, ei = pf.ei, ieps2 = pf.ieps2, ce2 = pf.ce2, ci2 = pf.ci2;
+  const double N = pf.N, t1 = pf.t1, S = pf.S, dop = pf.dop;
+  const double* xi = pf.xi; const double* zr = pf.zr; const double* zi = pf.zi; const double* dzr = pf.dzr; const double* dzi = pf.dzi;
+  const double* iki2 = pf.iki2; const double* gs = pf.gs;
   // ---- reverse ----
   // Accumulators with a DEFERRED wavefront-uniform factor (applied once per gradient point by lines_adjoint_finalize,
   // instead of once per point): LB.pref holds sum Sb S (x 1/pref), LB.i2wL holds sum PSQ wd (-> LB.wL, x -i2wL^2/2),

@@ -547,7 +547,9 @@ class Engine:
         L.check(self.lib, self.h, self.lib.tsff_set_option(self.h, L.OPT_DENOM_MODE, int(mode)))
 
     def set_launch_plan(self, plan: int):
-        """0: automatic (one 256-thread workgroup per (lineout, feature) when two fit a CU); 1: never interleave."""
+        """Bit mask (TSFF_OPT_LAUNCH_PLAN).  0: automatic (one 256-thread workgroup per (lineout, feature) when two fit a
+        CU; loss + gradient by the one-sweep kernel where its restrictions hold); bit 0: never interleave the features;
+        bit 1: always the two-sweep kernel."""
         L.check(self.lib, self.h, self.lib.tsff_set_option(self.h, L.OPT_LAUNCH_PLAN, int(plan)))
 
     def fp64_fma_peak_tflops(self) -> float:
