@@ -6,10 +6,17 @@ spectrum, batch 4096 per GPU, P = 6 free parameters (BASELINE.json metric, confi
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one evaluation of loss + gradient (tsff_loss_grad) over this rank's 4096 lineouts, with the
-inputs (params, data, amplitudes) already resident in HBM, plus -- for N > 1 -- the single RCCL
-all-reduce of [3 loss sums | gradient] (weak scaling: 4096 lineouts per GPU).  Rank 0 prints ONE JSON
-line.  The oracle is used only for the ``cpu_baseline`` leg (rank 0, N = 1).
+A step = one evaluation of loss + gradient (tsff_loss_grad_packed) over this rank's 4096 lineouts, with the
+inputs (params, data, amplitudes) already resident in HBM; the gradient kernels write [3 loss sums | gradient in the
+optimiser's ravel order over the global batch] straight into the buffer that -- for N > 1 -- the step's single RCCL
+all-reduce sums in place (weak scaling: 4096 lineouts per GPU).  Rank 0 prints ONE JSON line.  ``value`` is that
+HBM-resident rate; ``value_pcie_inclusive`` is the step SURVEY.md 8(d) describes (params host -> device and loss +
+gradient device -> host through pinned staging every step, as LossFunction.vg_loss does).  The oracle is used only for
+the ``cpu_baseline`` leg (rank 0, N = 1).
+
+Other lines (same schema, not the headline metric): ``--forward-only --batch 256`` (BASELINE configs[1]), ``--dlm``
+(per-lineout super-Gaussian order: W tables by the FP64 MFMA GEMM), ``--free-form``, ``--config4`` (BASELINE configs[3]:
+2-D angular form factor, 256 x 256 f_e, 512 angles x 1024 wavelengths).
 """
 from __future__ import annotations
 
@@ -75,6 +82,93 @@ def cpu_baseline(cfg, B, n_sample):
     }
 
 
+def config4_main(args):
+    """BASELINE configs[3]: non-Maxwellian f_e on a 256 x 256 velocity grid, 512 scattering angles x 1024 wavelengths, one
+    MI355X.  A step = one 2-D form-factor image (tsff_form_factor_2d: rotate the table by the angle of xi_e, project,
+    differentiate, interpolate, ratintn -- per (lambda, theta) point; FormFactor.calc_in_2D, form_factor.py:449-587) with the
+    table and parameters resident in HBM.  Parity of this path is UNPINNED against the reference (its ARTS goldens are
+    not in the reference tree): it is pinned to the oracle's restatement (tests/test_gpu_parity.py::test_config4_*)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tsadar_amd import synthetic as S
+    from tsadar_amd import ThomsonParams
+
+    nv, na, npts = 256, 512, 1024
+    cfg = S.baseline_deck()
+    sa = dict(sa=np.linspace(19.0, 139.0, na), weights=np.ones((1, na)) / na)
+    vx = np.linspace(-6 + 6.0 / nv, 6 - 6.0 / nv, nv)
+    Xg, Yg = np.meshgrid(vx, vx, indexing="ij")
+    f = np.exp(-((Xg / 1.3) ** 2 + (Yg / 0.8) ** 2) ** 1.4 / 2) + 0.05 * np.exp(-((Xg - 2.0) ** 2 + (Yg + 1.0) ** 2))
+    f /= f.sum() * (vx[1] - vx[0]) ** 2
+    ud_ang, va_ang = 25.0, -40.0
+    tp = ThomsonParams(cfg["parameters"], 1, batch=True, activate=False)
+    phys = tp.physical_matrix()
+    phys[0, 9] = 0.7   # a drift, so that the rotation angle varies over the image
+
+    cpu_res = None
+    if args.cpu_sample > 0:   # the oracle (NumPy restatement, one core) on a bounded sample: one wavelength x all 512 angles
+        from oracle import tsadar_oracle as orc
+
+        names = {"Te": 0, "ne": 1, "lam": 3, "amp1": 4, "amp2": 5, "amp3": 6, "ne_gradient": 7, "Te_gradient": 8, "ud": 9, "Va": 10}
+        p = {k: float(phys[0, s]) for k, s in names.items()}
+        p.update(Ti=[float(phys[0, 11])], Z=[float(phys[0, 12])], A=[float(phys[0, 13])], fract=[float(phys[0, 14])])
+        t0 = time.perf_counter()
+        orc.form_factor_2d(cfg["other"]["lamrangE"], npts, 0.0, sa["sa"], 1, p, vx, f, ud_ang, va_ang, lam_index=np.array([300]))
+        dt = time.perf_counter() - t0
+        cpu_res = {"value": na / dt / (npts * na), "unit": "images/s", "cores": 1, "kind": "port",
+                   "sample": f"{na} of the {npts * na} points of one image (wavelength index 300, all {na} angles) by the NumPy oracle "
+                             f"(restatement of calc_in_2D / rotate / calc_chi_vals), 1 core, {dt:.1f} s; scaled to whole images"}
+
+    import torch
+
+    from tsadar_amd.engine import Engine
+
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(0)
+    eng = Engine(cfg, sa, activate=False)
+    fd, Xd = eng.dev(f), eng.dev(phys)
+    P = torch.empty((1, 1, npts, na), dtype=torch.float64, device=eng.device)
+
+    def step():
+        return eng.form_factor_2d(0, Xd, fd, ud_ang, va_ang, out=P)
+
+    steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    eng.enable_timing(steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = eng.kernel_times_ms()
+    kavg_s = float(np.mean(kt)) * 1e-3
+    l1_peak = eng.l1_read_peak_tbps()
+    samples = float(npts) * na * nv * nv            # bicubic samples per image: every point rotates the whole table
+    stencil_bytes = samples * 16 * 8                # 4 x 4 doubles per sample, read through L1/L2 (the table is 532 KB)
+    flop = samples * 60.0                           # two Catmull-Rom weight sets (~24) + 16-term contraction (~36)
+    res = {
+        "metric": "2-D angular form-factor images/s (forward), 256x256 f_e, 512 angles x 1024 lambda",
+        "value": steps / dt, "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * dt / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[3]: arts-2d angular, non-Maxwellian f_e on a 256x256 v-grid, 512 scattering angles x 1024 lambda, "
+                               "one plasma condition (parity unpinned against the reference; pinned to the oracle)",
+                   "nv": nv, "n_angles": na, "n_lambda": npts, "points": npts * na, "bicubic_samples": samples},
+        "roofline": {"bound": "l1", "achieved": stencil_bytes / kavg_s / 1e12, "peak": l1_peak, "unit": "TB/s",
+                     "frac": stencil_bytes / kavg_s / 1e12 / l1_peak, "traffic": None,
+                     "kernel": "k_form_factor_2d<1,false,1,false> (table read through L1/L2 from the padded copy of k_pad2d)",
+                     "kernel_avg_ms": kavg_s * 1e3, "kernel_median_ms": float(np.median(kt)),
+                     "algorithmic_bytes_per_launch": stencil_bytes,
+                     "note": "achieved = 128 B of stencil per bicubic sample x samples / kernel time; peak = vector-L1 read rate measured on "
+                             "this device by tsff_l1_read_peak (16-byte loads from a 16 KB window); HBM traffic is the 532 KB table + 4 MB of P",
+                     "fp64_valu": {"achieved_tflops": flop / kavg_s / 1e12, "peak": FP64_PEAK / 1e12, "frac": flop / kavg_s / FP64_PEAK,
+                                   "flop_per_sample": 60.0}},
+    }
+    if cpu_res is not None:
+        res["cpu_baseline"] = cpu_res
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,8 +185,13 @@ def main():
     ap.add_argument("--free-form", action="store_true",
                     help="variant: explicit per-lineout f_e tables with the gradient w.r.t. f_e itself (Arbitrary1V-style "
                          "free-form distribution, nvx more unknowns per lineout; not the headline metric)")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE configs[3]: one 2-D angular form-factor image per step (256 x 256 f_e, 512 angles x 1024 lambda; "
+                         "parity-unpinned path, not the headline metric)")
     ap.add_argument("--plan", type=int, default=0, help="launch plan bit mask (experiments): 0 automatic, 1 never interleave the features, 2 two-sweep kernel instead of the one-sweep one")
     args = ap.parse_args()
+    if args.config4:
+        return config4_main(args)
     variant = args.dlm or args.free_form
 
     from tsadar_amd import synthetic as S
@@ -161,19 +260,21 @@ def main():
     w = eng.loss_weights(B * world, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
     terms = torch.empty(3, dtype=torch.float64, device=dev)
     grad = torch.empty((B, eng.NP), dtype=torch.float64, device=dev)
-    E_out = torch.empty((B, 1024), dtype=torch.float64, device=dev)
-    I_out = torch.empty((B, 1024), dtype=torch.float64, device=dev)
+    act_slots = [s for _, s in guess.slots.active_leaves]
+    # the buffer of the step's one collective and one D2H copy: [3 | P x B_global], written by the gradient kernels
+    packed = torch.zeros(3 + P * B * world, dtype=torch.float64, device=dev)
 
     def step():
         if args.forward_only:
             return eng.forward(X, batch["e_amps"], batch["i_amps"])
-        if args.free_form:
+        if args.free_form:  # (extra rows d loss / d f_e from a second kernel chain: packed by torch)
             gfe = eng.loss_grad(X, batch, w, gmask, fe=fe_dev, out=(terms, grad), want_fe_grad=True)[4]
             g = torch.cat([grad[:, act].t(), gfe.t()]).contiguous()
-        else:
-            eng.loss_grad(X, batch, w, gmask, out=(terms, grad))
-            g = grad[:, act].t().contiguous()
-        return D.allreduce_loss_grad(terms, g, world, rank)
+            return D.allreduce_loss_grad(terms, g, world, rank)
+        eng.loss_grad_packed(X, batch, w, gmask, act_slots, B * world, rank * B, out=packed)
+        if world > 1:
+            dist.all_reduce(packed)
+        return packed
 
     def fence():
         if world > 1:
@@ -197,20 +298,19 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
 
-    # PCIe-inclusive variant (what a host L-BFGS step pays): params H2D + loss/grad D2H every step
+    # PCIe-inclusive step (what a host L-BFGS step pays): params H2D + [loss | gradient] D2H every step
     pcie_value = None
     if world == 1 and not args.forward_only and not args.free_form:
         Xh = guess.to_matrix()
         eng.enable_timing(0)
         for _ in range(2):  # (allocates the pinned staging buffers)
-            eng.download(torch.cat([terms, grad[:, act].t().reshape(-1)]))
+            eng.download(packed)
             eng.upload(Xh)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            Xd = eng.upload(Xh)
-            eng.loss_grad(Xd, batch, w, gmask, out=(terms, grad))
-            host = eng.download(torch.cat([terms, grad[:, act].t().reshape(-1)]))
+            eng.loss_grad_packed(eng.upload(Xh), batch, w, gmask, act_slots, B, 0, out=packed)
+            host = eng.download(packed)
         torch.cuda.synchronize()
         pcie_value = B * args.steps / (time.perf_counter() - t1)
 
@@ -221,6 +321,7 @@ def main():
     fp64_measured = eng.fp64_fma_peak_tflops()  # micro-benchmark on this very device, outside the timed region
 
     kavg_s = float(np.mean(ktimes)) * 1e-3 if ktimes.size else float("nan")
+    kmed_ms = float(np.median(ktimes)) if ktimes.size else float("nan")
     # HBM bytes per launch from the PMC passes of this round (rocprofv3 --pmc cannot run inside bench.py):
     # profiles/r01_traffic.json, produced by scripts/profile_round.sh on the same workload
     traffic, tfile = None, None
@@ -273,9 +374,12 @@ def main():
             "traffic": traffic,
             "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % (os.path.basename(tfile) if tfile else "-"),
             "algorithmic_bytes_per_launch": B * abytes,
-            "kernel": ("k_spectrum<1,0,0,256,false>" if args.forward_only else "k_spectrum<1,1,GM,256,false> (one launch of 2B 256-thread workgroups)" if variant
-                       else "k_spectrum<1,1,0,256,false> (one launch of 2B 256-thread workgroups)"),
+            "kernel": ("k_spectrum<1,0,0,256,false>" if args.forward_only else
+                       ("k_spectrum<1,1,2,256,false> (two-sweep kernel with table adjoints)" if args.free_form else
+                        "k_spectrum_fused<1,%d,false> (one launch of 2B 256-thread workgroups, one sweep over the points)" % (1 if args.dlm else 0))
+                       if not (args.plan & 2) else "k_spectrum<1,1,GM,256,false> (two-sweep kernel)"),
             "kernel_avg_ms": kavg_s * 1e3,
+            "kernel_median_ms": kmed_ms,
             "algorithmic_bytes_per_spectrum": abytes,
             "note": "the path is FP64-VALU bound (SURVEY.md 8d); see roofline_fp64",
         },
@@ -292,6 +396,8 @@ def main():
     }
     if pcie_value is not None:
         res["value_pcie_inclusive"] = pcie_value
+        res["value_note"] = ("value: inputs resident in HBM, [3 | P x B] loss + gradient left in HBM; value_pcie_inclusive: + params "
+                             "H2D and [loss | gradient] D2H per step through pinned staging (SURVEY.md 8d protocol)")
     if cpu_res is not None:
         res["cpu_baseline"] = cpu_res
     print(json.dumps(res))

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define TSFF_ABI_VERSION 6
+#define TSFF_ABI_VERSION 7
 
 /* ---- parameter slots of one lineout: params[b][TSFF_NP(n_ion)] (normalised leaves of the
  * reference's ThomsonParams pytree, core/modules/ts_params.py:49-60,395-420,253-262) ---------- */
@@ -119,7 +119,8 @@ typedef struct tsff_config {
   int32_t n_taps_ele;
   int32_t tap_off_ele;
   const double *taps_ele;
-  int32_t n_taps_ion; /* 0 <=> spect_stddev_ion == 0 (irf.py:85: ThryI = modlI), not implemented */
+  int32_t n_taps_ion; /* 0 <=> spect_stddev_ion == 0 (irf.py:82-86): ThryI = modlI + noise_i, not convolved, not normalised, no
+                         amplitudes (needs npts == 1024, as in the reference where [npts] must match the [1024] data) */
   int32_t tap_off_ion;
   const double *taps_ion;
   int32_t norm; /* other.PhysParams.norm; only 0 is implemented */
@@ -268,6 +269,21 @@ int tsff_loss_grad(tsff_handle *h, const double *params, const double *fe, const
                    const double *weights, const uint8_t *grad_mask, double *loss_terms,
                    double *grad, double *ThryE, double *ThryI);
 
+/* tsff_loss_grad delivering the gradient the way the optimiser consumes it -- the flat vector of ravel_pytree that
+ * scipy L-BFGS-B iterates on (inverse/loops.py:40-54: trainable leaves outermost, lineouts innermost) over the GLOBAL
+ * batch of a lineout-sharded fit -- written straight into the buffer of the step's one all-reduce:
+ *   packed (device) [3 + n_active * B_global] = [S_iaw, S_blue, S_red | g[k][b]],  k < n_active, b < B_global;
+ *   active_slots (HOST) [n_active]: the parameter slot of each row k (the ravel order of the trainable leaves);
+ *   this call fills the loss sums of ITS B lineouts and the columns [b_offset, b_offset + B) of every row, and writes
+ *   zero to every other column: summed over the ranks (in place, no memset between steps) the buffer is the full
+ *   loss and gradient on every rank; with one rank (B_global == B, b_offset == 0) it is what LossFunction.vg_loss
+ *   returns after one device-to-host copy.  weights / grad_mask as for tsff_loss_grad. */
+int tsff_loss_grad_packed(tsff_handle *h, const double *params, const double *fe, const double *e_data,
+                          const double *i_data, const double *e_amps, const double *i_amps, const double *noise_e,
+                          const double *noise_i, int32_t B, const double *weights, const uint8_t *grad_mask,
+                          const int32_t *active_slots, int32_t n_active, int64_t B_global, int64_t b_offset,
+                          double *packed, double *ThryE, double *ThryI);
+
 /* The same plus the gradient w.r.t. the tabulated distribution function itself: grad_fe [B][nvx] (device) =
  * d loss / d fe[b][i], for fe_mode == TSFF_FE_PER_LINEOUT.  This is what equinox.filter_value_and_grad returns for the
  * leaves of a free-form distribution (Arbitrary1V.fval, core/modules/distribution_functions/base.py:157-204, filter
@@ -287,8 +303,8 @@ int tsff_array_loss(tsff_handle *h, const double *params, const double *fe, cons
                     const double *noise_e, const double *noise_i, int32_t B, double *sums,
                     double *sqdev_e, double *sqdev_i, double *ThryE, double *ThryI);
 
-/* HIP-event timing of the main kernel (k_spectrum) of tsff_forward / tsff_loss_grad /
- * tsff_array_loss on the handle's stream.  tsff_enable_timing(h, ring) keeps one event pair per
+/* HIP-event timing of the main kernel of tsff_forward / tsff_loss_grad(_packed, _fe) / tsff_array_loss (k_spectrum or
+ * k_spectrum_fused) and of tsff_form_factor_2d(_range, _save) (k_form_factor_2d) on the handle's stream.  tsff_enable_timing(h, ring) keeps one event pair per
  * launch in a ring of `ring` entries (0 disables); tsff_kernel_times returns the durations [ms] of
  * the most recent min(ring, launches, max_n) launches, oldest first, and synchronises on them. */
 int tsff_enable_timing(tsff_handle *h, int32_t ring);
@@ -299,6 +315,9 @@ int tsff_kernel_times(tsff_handle *h, float *ms, int32_t max_n, int32_t *n_out);
 int tsff_fp64_fma_peak(tsff_handle *h, double *tflops);
 /* the same on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the roof of k_wgemm */
 int tsff_fp64_mfma_peak(tsff_handle *h, double *tflops);
+/* micro-benchmark: sustained read rate of the vector L1 (every wavefront re-reads a 16 KB window with 16-byte loads) in
+ * TB/s over the whole device -- the roof of the 2-D sampler when its table is read through L1/L2 (nv > 128) */
+int tsff_l1_read_peak(tsff_handle *h, double *tbps);
 
 #ifdef __cplusplus
 }

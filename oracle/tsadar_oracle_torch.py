@@ -247,10 +247,13 @@ def ts_diag(cfg, sa, normed, batch, activate=True, fe_batch=None):
                 outE.append(y + col("noise_e", b))
                 lamE.append(lamb)
             else:
-                y = _irf(lam, modl, other["PhysParams"]["widIRF"]["spect_stddev_ion"])
-                y = y.reshape(1024, -1).mean(dim=1)
-                lamb = lam.reshape(1024, -1).mean(dim=1)
-                y = p["amp3"] * col("i_amps", b) * y / torch.amax(y)
+                if other["PhysParams"]["widIRF"]["spect_stddev_ion"]:
+                    y = _irf(lam, modl, other["PhysParams"]["widIRF"]["spect_stddev_ion"])
+                    y = y.reshape(1024, -1).mean(dim=1)
+                    lamb = lam.reshape(1024, -1).mean(dim=1)
+                    y = p["amp3"] * col("i_amps", b) * y / torch.amax(y)
+                else:   # irf.py:82-86: no ion IRF -> ThryI = modlI (un-normalised, un-binned)
+                    y, lamb = modl, lam
                 outI.append(y + col("noise_i", b))
                 lamI.append(lamb)
     z = torch.zeros((B, 1024), dtype=DT)

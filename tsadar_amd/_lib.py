@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsff.so")
 LIB_PATH = os.environ.get("TSFF_LIBRARY", LIB_PATH)  # A/B experiments: another in-tree build of the same ABI
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_ION = 4
 NBINS = 1024
 NXI1 = 1024
@@ -119,12 +119,15 @@ _SIGNATURES = {
     "tsff_ats_adjoint": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, c_double_p]),
     "tsff_forward": (C.c_int, [_vp] + [_vp] * 6 + [C.c_int32, _vp, _vp]),
     "tsff_loss_grad": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, _vp, _vp, _vp, _vp]),
+    "tsff_loss_grad_packed": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64,
+                                        _vp, _vp, _vp]),
     "tsff_loss_grad_fe": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, _vp, _vp, _vp, _vp, _vp]),
     "tsff_array_loss": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "tsff_enable_timing": (C.c_int, [_vp, C.c_int32]),
     "tsff_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "tsff_fp64_fma_peak": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "tsff_fp64_mfma_peak": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "tsff_l1_read_peak": (C.c_int, [_vp, C.POINTER(C.c_double)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -18,6 +18,7 @@ struct KStatic {
   int shared_fe;  // 1: every lineout uses table slot 0
   int loss_method;
   int load[2];
+  int raw[2];   // 1: no instrument response for this feature (irf.py:82-86, spect_stddev_ion == 0): Thry = modl + noise
   double lam_shift[2];
   const double* omgs[2];     // [npts] scattered-frequency axis (form_factor.py:134)
   const double* lam_bin[2];  // [1024] binned wavelength axis in nm (irf.py:75,125)

@@ -41,44 +41,71 @@ def init_from_env(backend: str | None = None):
 
 
 def shard_bounds(B_global: int, world: int, rank: int):
-    """Contiguous block [lo, hi) of rank ``rank``; the batch must divide evenly (the 1/N factor of
-    the loss assumes every rank holds B_global / world lineouts)."""
-    if B_global % world:
-        raise ValueError(f"global batch {B_global} does not divide over {world} ranks")
-    Bl = B_global // world
-    return rank * Bl, (rank + 1) * Bl
+    """Contiguous block [lo, hi) of rank ``rank``: chunks of ceil(B_global / world) lineouts, the last one(s) shorter or
+    empty when the batch does not divide evenly (reference batches are arbitrary, loops.py:133-146).  The 1/N of the loss
+    always uses the true global count (``Engine.loss_weights(B_global, ...)``)."""
+    chunk = -(-B_global // world)
+    lo = min(rank * chunk, B_global)
+    return lo, min(lo + chunk, B_global)
 
 
-def allreduce_loss_grad(terms, grad_local, world: int, rank: int, group=None):
+def allreduce_max(values, group=None):
+    """Max over the ranks of a few host scalars (the loss normalisers of a lineout-sharded fit) -> list of floats."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [float(v) for v in values]
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return [float(v) for v in t.cpu()]
+
+
+def pack_local(terms, grad_local, B_global: int, b_offset: int):
+    """[3] loss sums and [P, B_local] gradient rows of this rank -> the packed buffer ``[3 | P x B_global]`` of the step's
+    all-reduce with this rank's columns [b_offset, b_offset + B_local) filled and zeros elsewhere.  (The plain fit path gets
+    this buffer from the gradient kernels themselves, tsff_loss_grad_packed; this torch form serves the free-form f_e
+    variant, whose extra rows come from a second kernel chain.)"""
+    import torch
+
+    P, Bl = grad_local.shape
+    buf = torch.zeros(3 + P * B_global, dtype=grad_local.dtype, device=grad_local.device)
+    buf[:3] = terms
+    buf[3:].view(P, B_global)[:, b_offset:b_offset + Bl] = grad_local
+    return buf
+
+
+def allreduce_loss_grad(terms, grad_local, world: int, rank: int, group=None, B_global=None, b_offset=None):
     """terms: [3] un-weighted masked sums of this rank; grad_local: [P, B_local] (parameter-major).
-    Returns (terms_global [3], grad_global_flat [P * B_global]) -- identical on every rank.
+    Returns the packed ``[S_iaw, S_blue, S_red | grad (P x B_global)]`` -- identical on every rank.
 
-    The one collective of a fit step: a single all-reduce(sum) over ``[S_iaw, S_blue, S_red | grad (P x B_global)]``
-    in which every rank fills its own block of the gradient and zeros elsewhere (24 B + 8 P B_global bytes: 192 KiB
-    at one rank of 4096 lineouts, 1.5 MiB at eight)."""
+    The one collective of a fit step: a single all-reduce(sum) in which every rank fills its own block of the gradient
+    and zeros elsewhere (24 B + 8 P B_global bytes: 192 KiB at one rank of 4096 lineouts, 1.5 MiB at eight).  Shards
+    follow ``shard_bounds`` (uneven batches allowed) unless ``B_global`` / ``b_offset`` say otherwise."""
     import torch
 
     P, Bl = grad_local.shape
     if world == 1:
-        return terms, grad_local.reshape(-1)
+        return torch.cat([terms.reshape(3), grad_local.reshape(-1)])
     import torch.distributed as dist
 
-    buf = torch.zeros(3 + P * Bl * world, dtype=grad_local.dtype, device=grad_local.device)
-    buf[:3] = terms
-    buf[3:].view(P, world, Bl)[:, rank, :] = grad_local
+    if B_global is None:
+        B_global, b_offset = Bl * world, rank * Bl
+    buf = pack_local(terms, grad_local, B_global, b_offset)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    return buf[:3], buf[3:]
+    return buf
 
 
 def allgather_loss_grad(terms, grad_local, world: int, rank: int, group=None):
     """Same contract as allreduce_loss_grad with an all-gather of each rank's ``[3 + P B_local]`` block instead: half
     the bytes on the wire and no floating-point reduction in the collective (the three loss terms are summed in rank
-    order afterwards).  Kept as an alternative; the fit loop uses the all-reduce."""
+    order afterwards).  Equal shards only.  Kept as an alternative; the fit loop uses the all-reduce."""
     import torch
 
     P, Bl = grad_local.shape
     if world == 1:
-        return terms, grad_local.reshape(-1)
+        return torch.cat([terms.reshape(3), grad_local.reshape(-1)])
     import torch.distributed as dist
 
     mine = torch.cat([terms.reshape(3), grad_local.reshape(-1)])
@@ -89,7 +116,7 @@ def allgather_loss_grad(terms, grad_local, world: int, rank: int, group=None):
     for r in range(1, world):
         tot = tot + allb[r, :3]
     grad = allb[:, 3:].reshape(world, P, Bl).permute(1, 0, 2).reshape(-1)  # parameter-major over the global batch
-    return tot, grad
+    return torch.cat([tot, grad])
 
 
 def point_range(n_points: int, world: int, rank: int):

@@ -262,17 +262,24 @@ class Engine:
 
     # ---- host <-> device staging of the per-step vectors (pinned buffers: a fit step moves ~0.5 MB in and ~0.2 MB out) ----
     def upload(self, a: np.ndarray):
-        """NumPy array -> device tensor through a persistent pinned staging buffer (asynchronous copy on the current stream)."""
+        """NumPy array -> device tensor through a persistent pinned staging buffer (asynchronous copy on the current stream).
+        One device tensor per array SHAPE: the result aliases the previous upload of the same shape (a fit step consumes
+        its parameters before the next step uploads new ones); copy it if it must outlive the next call.  The pinned buffer is
+        not rewritten before its previous copy has completed (event per buffer)."""
         torch = self.torch
         a = np.ascontiguousarray(a, dtype=np.float64)
         key = ("in", a.shape)
         buf = self._staging.get(key)
         if buf is None:
-            buf = (torch.empty(a.shape, dtype=torch.float64).pin_memory(), torch.empty(a.shape, dtype=torch.float64, device=self.device))
+            buf = (torch.empty(a.shape, dtype=torch.float64).pin_memory(), torch.empty(a.shape, dtype=torch.float64, device=self.device),
+                   torch.cuda.Event())
             self._staging[key] = buf
-        pin, dev = buf
+        else:
+            buf[2].synchronize()   # (the earlier H2D copy out of this pinned buffer)
+        pin, dev, ev = buf
         pin.numpy()[...] = a
         dev.copy_(pin, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
         return dev
 
     def download(self, t) -> np.ndarray:
@@ -368,9 +375,12 @@ class Engine:
         if save and shared and nv <= 256:   # keep the projection records for form_factor_2d_grad(use_saved=True)
             rc = self.lib.tsff_form_factor_2d_save(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, float(ud_angle),
                                                    float(va_angle), B, int(lo), int(hi), self._ptr(P))
-            self._saved_2d = True
+            # the library ties the records to the buffers they were made from: keep those buffers (and what the caller
+            # passed) so that the adjoint can present the very same ones
+            keep = lambda a: a if isinstance(a, torch.Tensor) else np.array(a, dtype=np.float64, copy=True)
+            self._saved_2d = dict(phys_in=keep(phys), fe_in=keep(fe2d), phys_d=phys_d, fe_d=fe_d)
         else:
-            self._saved_2d = False
+            self._saved_2d = None
             rc = self.lib.tsff_form_factor_2d_range(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, int(shared),
                                                     float(ud_angle), float(va_angle), B, int(lo), int(hi), self._ptr(P))
         L.check(self.lib, self.h, rc)
@@ -382,9 +392,14 @@ class Engine:
         (grad_phys [B, NP], grad_fe2d [nv, nv] or None) as device tensors.  ``point_range = (begin, end)``: the
         contributions of that slice of the flat point list only (to be summed over the ranks of a node)."""
         torch = self.torch
-        phys_d = self.dev(phys).reshape(-1, self.NP)
+        saved = getattr(self, "_saved_2d", None) if use_saved else None
+        if saved is not None and self._same_input(phys, saved["phys_in"], saved["phys_d"]) and self._same_input(fe2d, saved["fe_in"], saved["fe_d"]):
+            phys_d, fe_d = saved["phys_d"], saved["fe_d"]   # the buffers the projection records were made from
+        else:   # other inputs than the saving forward saw (or no records): the adjoint does its own sampling
+            saved = None
+            phys_d, fe_d = self.dev(phys).reshape(-1, self.NP), self.dev(fe2d)
         B = phys_d.shape[0]
-        fe_d, Pb = self.dev(fe2d), self.dev(Pbar)
+        Pb = self.dev(Pbar)
         assert fe_d.dim() == 2 and fe_d.shape[0] == fe_d.shape[1]
         nv = int(fe_d.shape[0])
         gp = torch.empty((B, self.NP), dtype=torch.float64, device=self.device)
@@ -392,10 +407,21 @@ class Engine:
         self._sync_stream()
         lo, hi = point_range if point_range is not None else (0, -1)
         rc = self.lib.tsff_form_factor_2d_grad(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, float(ud_angle),
-                                               float(va_angle), B, int(lo), int(hi), int(bool(use_saved) and getattr(self, "_saved_2d", False)),
+                                               float(va_angle), B, int(lo), int(hi), int(saved is not None),
                                                self._ptr(Pb), self._ptr(gp), self._ptr(gf))
         L.check(self.lib, self.h, rc)
         return gp, gf
+
+    def _same_input(self, a, ref, ref_dev) -> bool:
+        """Is ``a`` what the saving forward was given?  A host array equal to the copy kept at the save, or a device tensor on
+        the same memory (a device tensor rewritten in place between the two calls cannot be told apart: do not do that)."""
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            return a is ref or (a.is_cuda and a.data_ptr() == ref_dev.data_ptr() and a.numel() == ref_dev.numel())
+        if isinstance(ref, torch.Tensor):
+            return False
+        a = np.asarray(a)
+        return a.size == ref.size and bool(np.array_equal(a.reshape(ref.shape), ref))
 
     def ats_setup(self, weights, ang_axis, stddev_lam, stddev_ang, lam_step=1, ang_step=1, row_start=0, row_end=None,
                   irf_cutoff_sigmas=12.0):
@@ -522,6 +548,40 @@ class Engine:
         L.check(self.lib, self.h, rc)
         return terms, grad, E, I
 
+    def loss_grad_packed(self, params, batch, weights, grad_mask, active_slots, B_global=None, b_offset=0, want_spectra=False, out=None):
+        """tsff_loss_grad_packed: -> (packed [3 + P * B_global] CUDA tensor, ThryE, ThryI).  packed = [S_iaw, S_blue, S_red |
+        gradient, trainable leaves outermost, lineouts of the GLOBAL batch innermost]; this rank's B lineouts fill the
+        columns [b_offset, b_offset + B), every other column is written as zero -- the buffer of the step's one in-place
+        all-reduce and of the single device-to-host copy.  The buffer is persistent per (P, B_global)."""
+        torch = self.torch
+        X = self.dev(params).reshape(-1, self.NP)
+        B = X.shape[0]
+        Bg = int(B_global) if B_global is not None else B
+        act = np.ascontiguousarray(active_slots, dtype=np.int32)
+        ea = self._vec(batch["e_amps"], B) if self.load_ele else None
+        ia = self._vec(batch["i_amps"], B) if self.load_ion else None
+        ed = self._mat(batch["e_data"], B) if self.load_ele else None
+        idt = self._mat(batch["i_data"], B) if self.load_ion else None
+        ne_, ni_ = self._mat(batch.get("noise_e"), B), self._mat(batch.get("noise_i"), B)
+        if out is None:
+            key = ("packed", act.size, Bg)
+            out = self._staging.get(key)
+            if out is None:
+                out = torch.zeros(3 + act.size * Bg, dtype=torch.float64, device=self.device)
+                self._staging[key] = out
+        assert out.numel() == 3 + act.size * Bg and out.is_contiguous()
+        E = torch.zeros((B, L.NBINS), dtype=torch.float64, device=self.device) if want_spectra else None
+        I = torch.zeros((B, L.NBINS), dtype=torch.float64, device=self.device) if want_spectra else None
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        gm = np.ascontiguousarray(grad_mask, dtype=np.uint8)
+        self._sync_stream()
+        rc = self.lib.tsff_loss_grad_packed(self.h, self._ptr(X), None, self._ptr(ed), self._ptr(idt), self._ptr(ea), self._ptr(ia),
+                                            self._ptr(ne_), self._ptr(ni_), B, w.ctypes.data_as(L.c_double_p), gm.ctypes.data_as(L.c_uint8_p),
+                                            act.ctypes.data_as(C.POINTER(C.c_int32)), int(act.size), Bg, int(b_offset), self._ptr(out),
+                                            self._ptr(E), self._ptr(I))
+        L.check(self.lib, self.h, rc)
+        return out, E, I
+
     def array_loss(self, params, batch, fe=None):
         torch = self.torch
         X = self.dev(params).reshape(-1, self.NP)
@@ -556,6 +616,13 @@ class Engine:
         """Measured FP64 vector FMA rate of this device (micro-benchmark, TFLOP/s)."""
         v = C.c_double()
         L.check(self.lib, self.h, self.lib.tsff_fp64_fma_peak(self.h, C.byref(v)))
+        return float(v.value)
+
+    def l1_read_peak_tbps(self) -> float:
+        """Measured vector-L1 read rate of this device (micro-benchmark, TB/s): the roof of the 2-D sampler for tables read
+        through L1/L2."""
+        v = C.c_double()
+        L.check(self.lib, self.h, self.lib.tsff_l1_read_peak(self.h, C.byref(v)))
         return float(v.value)
 
     def fp64_mfma_peak_tflops(self) -> float:

@@ -18,13 +18,20 @@ from .params import ThomsonParams
 
 class LossFunction:
     def __init__(self, cfg: Dict, scattering_angles, dummy_batch, process_group=None, distributed: bool = False):
-        """``distributed=True``: this process holds one contiguous shard of the lineouts (rank r owns
-        lineouts [r*B_local, (r+1)*B_local) of the global batch); ``vg_loss`` then takes and returns
-        GLOBAL flat vectors and every rank gets the full loss and gradient."""
+        """``distributed=True``: this process holds one contiguous shard of the lineouts (rank r owns the lineouts
+        ``distributed.shard_bounds(B_global, world, r)`` of the global batch; the batch need not divide evenly);
+        ``vg_loss`` then takes and returns GLOBAL flat vectors and every rank gets the full loss and gradient.
+        ``dummy_batch`` may be the rank's LOCAL shard, as in the reference pattern ``LossFunction(cfg, sa, batch)``: the
+        loss normalisers (the maxima of the data, loss_function.py:88-92) are then max-reduced over the ranks, so that every
+        rank weighs the loss identically -- they are baked into the gradient kernel's weights."""
         self.cfg = cfg
+        self.distributed = distributed
+        self.pg = process_group
         if cfg["optimizer"]["y_norm"]:  # loss_function.py:88-92
             self.i_norm = float(np.amax(dummy_batch["i_data"]))
             self.e_norm = float(np.amax(dummy_batch["e_data"]))
+            if distributed:
+                self.i_norm, self.e_norm = D.allreduce_max([self.i_norm, self.e_norm], process_group)
         else:
             self.i_norm = self.e_norm = 1.0
         if cfg["optimizer"].get("x_norm") and cfg.get("nn", {}).get("use"):
@@ -38,8 +45,6 @@ class LossFunction:
         self.fd_step = 1e-5  # normalised units; central differences of the 1-D angular model (see _vg_angular)
         self.force_fd = False  # True: central differences for 2-D distribution functions too (cross-check of the adjoint)
         self.ts_diag = ThomsonScatteringDiagnostic(cfg, scattering_angles=scattering_angles)
-        self.distributed = distributed
-        self.pg = process_group
         if self.angular and distributed:
             # 2-D angular decks: every rank holds the whole (single) plasma condition; the (lambda, theta) point list of the
             # form factor and of its adjoint is what gets sharded (one all-gather forward, one all-reduce backward)
@@ -48,7 +53,7 @@ class LossFunction:
             self.ts_diag.dist = (dist.get_world_size(process_group), dist.get_rank(process_group), process_group)
         self.unravel_weights = None  # set by the caller exactly as in loops.py:41
         self._gfe = None
-        self._dev_batch_key = None
+        self._dev_batch_src = None   # the batch arrays the device-resident copies were made from (strong references)
         self._dev_batch = None
 
     # ---- helpers ------------------------------------------------------------------------------
@@ -59,17 +64,29 @@ class LossFunction:
 
         return dist.get_world_size(self.pg), dist.get_rank(self.pg)
 
+    _BATCH_KEYS = ("e_amps", "i_amps", "e_data", "i_data", "noise_e", "noise_i")
+
     def _device_batch(self, eng, batch, B):
-        """Data stay resident on the GPU for the whole fit: convert once per batch object."""
-        key = (id(batch), B)
-        if self._dev_batch_key != key:
+        """Data stay resident on the GPU for the whole fit: converted once per set of batch ARRAYS.  The cache is keyed by
+        the identity of the arrays themselves and holds references to them, so a recycled ``id`` of a freed dict or array
+        can never alias another batch (the reference feeds freshly built dicts through one loss function, loops.py:133-146,
+        postprocess.py:140-149).  Arrays rewritten IN PLACE are not noticed: call ``invalidate_batch()`` after doing that."""
+        src = tuple(batch.get(k) for k in self._BATCH_KEYS)
+        old = self._dev_batch_src
+        if old is None or old[0] != B or len(old[1]) != len(src) or any(a is not b for a, b in zip(old[1], src)):
             d = {}
             for k in ("e_amps", "i_amps"):
                 d[k] = eng._vec(batch[k], B)
             for k in ("e_data", "i_data", "noise_e", "noise_i"):
                 d[k] = eng._mat(batch.get(k), B)
-            self._dev_batch, self._dev_batch_key = d, key
+            self._dev_batch, self._dev_batch_src = d, (B, src)
         return self._dev_batch
+
+    def invalidate_batch(self):
+        """Forget the device-resident copy of the batch (after modifying batch arrays in place)."""
+        self._dev_batch_src = None
+        self._dev_batch = None
+        self._ang_dev_src = None
 
     def _evaluate(self, ts_params: ThomsonParams, batch, want_spectra=False):
         """Local shard: -> (value, grad[B_local, NP] numpy, ThryE, ThryI).  In distributed mode the
@@ -94,6 +111,21 @@ class LossFunction:
         self._gfe = None
         terms, grad, E, I = eng.loss_grad(X, db, w, ts_params.grad_mask(), want_spectra=want_spectra)
         return eng, w, terms, grad, E, I
+
+    def _evaluate_packed(self, ts_params: ThomsonParams, batch, act, B_global, b_offset, want_spectra=False):
+        """Local shard -> (engine, weights, packed device tensor [3 + P * B_global], ThryE, ThryI): the loss sums and the
+        gradient in ravel order over the global batch, this rank's columns filled and the others zero, written by the
+        gradient kernels themselves (tsff_loss_grad_packed) -- the buffer of the one all-reduce and of the one
+        device-to-host copy of a step."""
+        eng = self.ts_diag.engine(ts_params.activate)
+        X = ts_params.to_matrix()
+        B = X.shape[0]
+        w = eng.loss_weights(B_global, self.i_norm, self.e_norm, self.cfg["data"]["ion_loss_scale"])
+        if B == 0:   # (more ranks than lineouts: this rank only takes part in the collective)
+            return eng, w, eng.torch.zeros(3 + len(act) * B_global, dtype=eng.torch.float64, device=eng.device), None, None
+        db = self._device_batch(eng, batch, B)
+        packed, E, I = eng.loss_grad_packed(eng.upload(X), db, w, ts_params.grad_mask(), act, B_global, b_offset, want_spectra=want_spectra)
+        return eng, w, packed, E, I
 
     # ---- angular (ARTS) decks ------------------------------------------------------------------
     def _angular_value(self, ts_params: ThomsonParams, batch, want_bar=False):
@@ -144,8 +176,9 @@ class LossFunction:
         torch = eng.torch
         self.ts_diag._angular(eng, ts_params, batch, to_host=False)
         ctx = self.ts_diag._angular_ctx
-        key = id(batch["e_data"])
-        if getattr(self, "_ang_dev_key", None) != key:
+        src = (batch["e_data"], batch["noise_e"])   # (strong references: see _device_batch)
+        old_src = getattr(self, "_ang_dev_src", None)
+        if old_src is None or old_src[0] is not src[0] or old_src[1] is not src[1]:
             lamE = ctx["lamE"]
             ext, r = self.cfg["other"]["extraoptions"], self.cfg["data"]["fit_rng"]
             rows = ctx["E_dev"].shape[0]
@@ -160,7 +193,7 @@ class LossFunction:
                 wcol *= 0.5
             self._ang_dev = dict(d=eng.dev(np.ascontiguousarray(batch["e_data"], dtype=np.float64)), wcol=eng.dev(wcol)[None, :],
                                  noise=eng.dev(np.array(np.atleast_1d(np.asarray(batch["noise_e"], dtype=np.float64)))))
-            self._ang_dev_key = key
+            self._ang_dev_src = src
         dv = self._ang_dev
         Et = ctx["E_dev"] + dv["noise"]
         d, un, method = dv["d"], self.e_norm**2, self.cfg["optimizer"]["loss_method"]
@@ -272,23 +305,29 @@ class LossFunction:
         if lbfgs:
             diff_weights = self.unravel_weights(np.asarray(diff_weights, dtype=np.float64))
         diff_global = diff_weights
+        Bg = int(diff_weights.values[0].shape[0])
+        lo, hi = D.shard_bounds(Bg, world, rank) if world > 1 else (0, Bg)
         if world > 1:
             # global -> local slice of every trainable leaf
-            lo, hi = D.shard_bounds(diff_weights.values[0].shape[0], world, rank)
             diff_weights = tree.DiffParams(diff_weights.slots, [v[lo:hi] for v in diff_weights.values])
         ts_params = tree.combine(static_weights, diff_weights)
-        eng, w, terms, grad, E, I = self._evaluate(ts_params, batch, want_spectra=not lbfgs)
         act = [s for _, s in ts_params.slots.active_leaves]
-        gact = grad[:, act].t().contiguous()  # [P, B_local], ravel order
-        if getattr(self, "_gfe", None) is not None and ts_params.slots.fval_active:
-            gact = torch.cat([gact, self._gfe.t().contiguous()])  # nvx more rows: d loss / d fe, chained on the host
-        terms, gflat = D.allreduce_loss_grad(terms, gact, world, rank, self.pg)  # the one collective per step
-        out = torch.cat([terms, gflat])  # single D2H copy: 3 + P*B doubles (pinned staging on the engine)
-        host = eng.download(out) if hasattr(eng, "download") else out.cpu().numpy()
+        if ts_params.fval is not None and ts_params.slots.fval_active:
+            # free-form f_e: nvx more rows (d loss / d fe, chained on the host); packed by torch, one all-reduce all the same
+            eng, w, terms, grad, E, I = self._evaluate(ts_params, batch, want_spectra=not lbfgs)
+            gact = torch.cat([grad[:, act].t(), self._gfe.t()]).contiguous()  # [P + nvx, B_local], ravel order
+            out = D.allreduce_loss_grad(terms, gact, world, rank, self.pg, B_global=Bg, b_offset=lo)
+            host = eng.download(out)
+            flat = self._chain_fval(host[3:], len(act), diff_global)
+        else:
+            eng, w, out, E, I = self._evaluate_packed(ts_params, batch, act, Bg, lo, want_spectra=not lbfgs)
+            if world > 1:  # the one collective per step, in place on the buffer the kernels wrote
+                import torch.distributed as dist
+
+                dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.pg)
+            host = eng.download(out)  # single D2H copy: 3 + P * B_global doubles (pinned staging on the engine)
+            flat = host[3:]
         value = float(np.dot(host[:3], w))
-        flat = host[3:]
-        if getattr(self, "_gfe", None) is not None and ts_params.slots.fval_active:
-            flat = self._chain_fval(flat, len(act), diff_global)
         if lbfgs:
             return value, flat
         aux = [E.cpu().numpy() if E is not None else None, ts_params()]
