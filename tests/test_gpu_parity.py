@@ -1120,24 +1120,57 @@ def test_angular_vg_loss_finite_difference(torch_mod):
     # (step 1e-5 of the fallback straddles kinks of the table lookups: it is the less accurate of the two)
     # (value: host NumPy sums on the fallback path, device sums on the adjoint path)
     assert abs(v2 - val) < 1e-13 * abs(val) and np.max(np.abs(g2 - g)) < 1e-2 * np.max(np.abs(g)), (g2, g)
-    # the reference's round trip on two parameters (Te, ne; the DLM order held at its true value)
+    # ---- L-BFGS-B on two parameters (Te, ne; the DLM order held at its true value), noise-free data ----
+    # The image loss of the reference's angular path (row-max normalisation, resolution-unit means, table lookups) is
+    # extremely ill-conditioned: its gradient changes by 0.6 % over 1e-6 in x a few steps from the start (difference
+    # quotients with h = 1e-5 are off by 8 % there), the (Te, ne) plane holds several local minima within 0.02 of the truth,
+    # and the line search jumps across them -- driven by the ORACLE's loss with central differences the same start ends at
+    # 0.16 of the initial loss (h = 1e-6) while the adjoint-driven run ends at 0.035: which minimum is reached depends on the
+    # last bits (tests/golden/make_angular_lbfgs.py has the study).  So the check is on what IS determined: (i) the first
+    # iterates equal the oracle-driven ones (committed fixture, central differences with h = 1e-7) to 1e-6, before the
+    # sensitivity amplifies rounding by ~500x per iteration; (ii) the run ends at a stationary point of the ORACLE's loss
+    # with a lower value -- i.e. it stopped because the model has a minimum there, not because of a wrong gradient.
     cfg["parameters"]["electron"]["fe"]["active"] = False
+    fix = np.load("tests/golden/angular_lbfgs_oracle.npz")
     truth2 = orc.init_normed_params(cfg["parameters"], 1, True)
-    truth2["Te"] = truth2["Te"] - 0.2   # (inside the basin of the truth: the max-normalised image loss is multi-modal in (Te, ne))
+    truth2["Te"] = truth2["Te"] - 0.2
     truth2["ne"] = truth2["ne"] + 0.12
-    batch2 = dict(batch, e_data=oracle_image(truth2, np.ones((100, 1)))[0])
+    np.testing.assert_allclose([truth2["Te"][0], truth2["ne"][0]], fix["x_truth"], rtol=0, atol=1e-14)
+    data2 = oracle_image(truth2, np.ones((100, 1)))[0]
+    batch2 = dict(batch, e_data=data2)
     fit_fn = LossFunction(cfg, sa, batch2)
     tp2 = ThomsonParams(cfg["parameters"], 1, batch=False, activate=True)
     diff2, static2 = tree.partition(tp2, tree.get_filter_spec(cfg["parameters"], tp2))
     x2, fit_fn.unravel_weights = tree.ravel_pytree(diff2)
-    assert x2.size == 2
-    v0 = fit_fn.vg_loss(x2, static2, batch2)[0]
-    res = minimize(fit_fn.vg_loss, x2, args=(static2, batch2), method="L-BFGS-B", jac=True,
-                   options={"maxiter": 60, "ftol": 1e-15, "gtol": 1e-12})
-    # (the image loss has kinks -- table cells, row arg-max -- where the line search of L-BFGS-B can stall close to the truth)
-    # (where exactly it stalls depends on the last bits of the arithmetic: the bound is loose on purpose)
-    assert res.fun < 0.1 * v0, (res.x, res.fun, v0, res.nit)
-    np.testing.assert_allclose(res.x, [truth2["Te"][0], truth2["ne"][0]], atol=8e-2)
+    assert x2.size == 2 and np.allclose(x2, fix["x_start"], rtol=0, atol=1e-14)
+    its = []
+
+    def vg(x, *a):
+        v, g = fit_fn.vg_loss(x, *a)
+        its.append(np.concatenate([x, [v], g]))
+        return v, g
+
+    res = minimize(vg, x2, args=(static2, batch2), method="L-BFGS-B", jac=True, options={"maxiter": 60, "ftol": 1e-15, "gtol": 1e-12})
+    its, ref = np.array(its), fix["iterates"]
+    v0, g0 = its[0, 2], np.max(np.abs(its[0, 3:]))
+    for k in range(3):   # (i)
+        assert np.max(np.abs(its[k, :2] - ref[k, :2])) < 1e-6, (k, its[k], ref[k])
+        assert abs(its[k, 2] - ref[k, 2]) < 1e-3 * ref[k, 2], (k, its[k], ref[k])
+    assert np.max(np.abs(its[0, 3:] - ref[0, 3:])) < 1e-6 * g0 and np.max(np.abs(its[1, 3:] - ref[1, 3:])) < 1e-3 * np.max(np.abs(ref[1, 3:]))
+
+    def oracle_loss2(x):
+        n = orc.init_normed_params(cfg["parameters"], 1, True)
+        n["Te"], n["ne"] = np.array([x[0]]), np.array([x[1]])
+        E, lam_o = oracle_image(n, batch["e_amps"])
+        err = np.square(data2 - E) / fit_fn.e_norm**2
+        r = cfg["data"]["fit_rng"]
+        return 0.5 * (np.mean(err[:, (lam_o > r["blue_min"]) & (lam_o < r["blue_max"])]) + np.mean(err[:, (lam_o > r["red_min"]) & (lam_o < r["red_max"])]))
+
+    h = 1e-7   # (ii)
+    g_end = np.array([(oracle_loss2(res.x + h * e) - oracle_loss2(res.x - h * e)) / (2 * h) for e in np.eye(2)])
+    assert abs(oracle_loss2(res.x) - res.fun) < 1e-7 * res.fun
+    assert np.max(np.abs(g_end)) < 1e-4 * g0 and np.max(np.abs(res.jac)) < 1e-4 * g0, (res.x, g_end, res.jac, g0)
+    assert res.fun < 0.5 * v0, (res.x, res.fun, v0, res.nit)
 
 
 @pytest.mark.parametrize("B", [37, 256, 4096])
