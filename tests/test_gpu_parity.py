@@ -1780,3 +1780,33 @@ def test_reference_angular_decks_against_oracle_fixture(torch_mod, tag):
     err = np.max(np.abs(E[z["rows"]] - ref)) / np.max(np.abs(ref))
     assert err < 1e-7, err
     np.testing.assert_allclose(E[z["rows"]], ref, rtol=1e-4, atol=1e-9 * np.max(ref))   # the reference's own tolerance form
+
+
+def test_loss_grad_packed_layout(torch_mod):
+    """tsff_loss_grad_packed: [S_iaw, S_blue, S_red | g[k][b_global]] with this call's B lineouts in the columns
+    [b_offset, b_offset + B) of every row (ravel order of the trainable leaves) and ZERO in every other column -- also
+    when the buffer held something else before (it is all-reduced in place step after step) -- for the one-sweep and the
+    two-sweep kernel; equal to tsff_loss_grad's per-lineout gradient bit for bit."""
+    torch = torch_mod
+    cfg = decks.deck_fit()
+    B, Bg, off = 5, 13, 6
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B, seed=61)
+    eng = _engine(cfg, sa)
+    X = util.normed_to_matrix(normed, 1)
+    gm = eng.slots.active.astype(np.uint8)
+    act = [s for s in range(eng.NP) if gm[s]][::-1]   # any order of the rows is the caller's choice
+    w = eng.loss_weights(Bg, i_norm, e_norm)
+    for plan in (0, 2, 1):
+        eng.set_launch_plan(plan)
+        terms, grad, _, _ = eng.loss_grad(X, batch, w, gm)
+        out = torch.full((3 + len(act) * Bg,), 7.0, dtype=torch.float64, device=eng.device)
+        packed, E, I = eng.loss_grad_packed(X, batch, w, gm, act, Bg, off, want_spectra=True, out=out)
+        p = packed.cpu().numpy()
+        assert np.array_equal(p[:3], terms.cpu().numpy())
+        rows = p[3:].reshape(len(act), Bg)
+        assert np.array_equal(rows[:, off:off + B], grad.cpu().numpy()[:, act].T), plan
+        assert np.all(rows[:, :off] == 0.0) and np.all(rows[:, off + B:] == 0.0)
+        assert E is not None and bool(torch.isfinite(E).all())
+    eng.set_launch_plan(0)
+    with pytest.raises(L.TsffError, match="packed-output"):
+        eng.loss_grad_packed(X, batch, w, gm, act, Bg, Bg - 2)   # columns past the end of the global batch
