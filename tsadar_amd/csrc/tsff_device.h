@@ -139,8 +139,13 @@ struct Tables {
   double* Hy;          // [nvx]  adjoint of the ln fe node values
   double* Hs;          // [nvx]  adjoint of the ln fe node slopes
   double vx0, dv, idv, vxlast;
+  double u0, utop;     // -vx0 / dv and (nvx - 1)(1 - 2^-52): hermite_lookup_c's position in cell units and its clamp
   int nvx;
 };
+__device__ __forceinline__ void tables_set_grid(Tables& T, double vx0, double dv, int nvx) {
+  T.vx0 = vx0; T.dv = dv; T.idv = 1.0 / dv; T.vxlast = vx0 + (nvx - 1) * dv; T.nvx = nvx;
+  T.u0 = -vx0 * T.idv; T.utop = (double)(nvx - 1) * (1.0 - 1.1102230246251565e-16);
+}
 
 // Gradient w.r.t. the tabulated distribution function (GM == 2): every point scatters the adjoint of its two table
 // lookups into the table adjoints in LDS.  Neighbouring points of one thread fall into the same table interval most of
@@ -191,23 +196,19 @@ __device__ __forceinline__ void fe_add_h(FeAcc& a, const Tables& T, double x, do
 // jnp.interp(xie, xi2, W): clamps to the end values outside the table (form_factor.py:270)
 __device__ __forceinline__ void w_lookup(const double* W, double xe, double& w, double& dw) {
 #pragma clang fp contract(off)   // (every rounding that reaches a spectrum is written out: the same bits from every kernel)
-  const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
-  double u = (xe - kXi2_0) * kXi2_ih;
-  int i = (int)u;
-  i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
-  double t = (xe - __builtin_fma((double)i, kXi2_h, kXi2_0)) * kXi2_ih;
+  // position in cell units, clamped into the table: outside it the clamped cell reproduces the end value (t = 0 at the left
+  // end, t = 1 - 2^-52 at the right end) -- floor / subtract instead of convert-back / multiply-add, and ONE comparison
+  // (clamped or not) for the slope (round 2: 6 instructions where the index arithmetic took 10)
+  constexpr double kTop = (double)(kNXi2 - 1) * (1.0 - 1.1102230246251565e-16);
+  const double u = __builtin_fma(xe, kXi2_ih, -kXi2_0 * kXi2_ih);
+  const double uc = fmin(fmax(u, 0.0), kTop);
+  const double fl = __builtin_floor(uc);
+  const double t = uc - fl;
+  const int i = (int)fl;
   const double a = W[i], b = W[i + 1];
-#if TSFF_BRANCHFREE
-  // straight-line form: one scheduling region per point, so the LDS reads can be hoisted over the arithmetic
-  t = fmin(fmax(t, 0.0), 1.0);  // outside the table the clamped interval reproduces the end value
   const double d = b - a;
   w = __builtin_fma(t, d, a);
-  dw = (xe < kXi2_0 || xe > xlast) ? 0.0 : d * kXi2_ih;
-#else
-  if (xe < kXi2_0) { w = W[0]; dw = 0.0; }
-  else if (xe > xlast) { w = W[kNXi2 - 1]; dw = 0.0; }
-  else { w = a + t * (b - a); dw = (b - a) * kXi2_ih; }
-#endif
+  dw = (u == uc) ? d * kXi2_ih : 0.0;
 }
 
 // cubic coefficients of interval i of the Hermite interpolant in t = (x - vx_i)/dv:
@@ -221,12 +222,15 @@ __device__ __forceinline__ void hermite_coeffs(double2 a, double2 b, double dv, 
 // the same lookup as hermite_lookup() below from the per-interval coefficient table
 __device__ __forceinline__ void hermite_lookup_c(const Tables& T, double x, double& H, double& dH) {
 #pragma clang fp contract(off)
-  const double u = (x - T.vx0) * T.idv;
-  int i = (int)u;
-  i = i < 0 ? 0 : (i > T.nvx - 2 ? T.nvx - 2 : i);
-  const double t = (x - __builtin_fma((double)i, T.dv, T.vx0)) * T.idv;
+  // (same index arithmetic as w_lookup; T.u0 = -vx0 / dv, T.utop = (nvx - 1)(1 - 2^-52): a position that the clamp moves
+  //  lies outside the grid, where the interpolant is the constant -50)
+  const double u = __builtin_fma(x, T.idv, T.u0);
+  const double uc = fmin(fmax(u, 0.0), T.utop);
+  const double fl = __builtin_floor(uc);
+  const double t = uc - fl;
+  const int i = (int)fl;
   const double2 c01 = T.hc[2 * i], c23 = T.hc[2 * i + 1];
-  const bool out = x < T.vx0 || x > T.vxlast;
+  const bool out = u != uc;
   const double Hi = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, c23.y, c23.x), c01.y), c01.x);
   const double dHi = __builtin_fma(t, __builtin_fma(3.0 * t, c23.y, 2.0 * c23.x), c01.y) * T.idv;
   H = out ? -50.0 : Hi;
@@ -267,6 +271,7 @@ struct LineS {
   double i2wL;  // 2 / wL (derived; carries no adjoint of its own)
   double m;     // adjoint accumulator of the DLM order (through the ln f_e and W tables); unused in the forward
   double ixi[NI], a_i[NI], cs[NI];
+  double hai[NI];   // -a_i / 2 (derived: chi_i = sum hai ik^2 Z'; carries no adjoint of its own)
 };
 
 // gradient-point factor: linspace(1 - v/200, 1 + v/200, G)[g] = 1 + v*cg   (form_factor.py:182-195)
@@ -299,6 +304,7 @@ __device__ __forceinline__ void make_lines(const Phys<NI>& p, double lam_shift, 
     L.ixi[s] = 1.0 / (kSqrt2 * vTi);
     L.a_i[s] = kC0sq * kMe * p.Z[s] * p.Z[s] * p.fr[s] * ne_g / (Zbar * p.Ti[s]);
     L.cs[s] = p.fr[s] * p.Z[s] * p.Z[s] / (Zbar * vTi);
+    L.hai[s] = -0.5 * L.a_i[s];
   }
 }
 
@@ -309,7 +315,7 @@ __device__ __forceinline__ void make_lines_uniform(const Phys<NI>& p, double lam
   L.wpe2 = uni(L.wpe2); L.wL = uni(L.wL); L.i2wL = uni(L.i2wL); L.kL = uni(L.kL); L.ivTe = uni(L.ivTe);
   L.a_e = uni(L.a_e); L.pref = uni(L.pref); L.Ud = uni(L.Ud); L.Vd = uni(L.Vd);
 #pragma unroll
-  for (int s = 0; s < NI; ++s) { L.ixi[s] = uni(L.ixi[s]); L.a_i[s] = uni(L.a_i[s]); L.cs[s] = uni(L.cs[s]); }
+  for (int s = 0; s < NI; ++s) { L.ixi[s] = uni(L.ixi[s]); L.a_i[s] = uni(L.a_i[s]); L.cs[s] = uni(L.cs[s]); L.hai[s] = uni(L.hai[s]); }
 }
 
 // adjoint of make_lines: LB holds dL/d(LineS fields) summed over the points of gradient point g;
@@ -386,11 +392,13 @@ __device__ __forceinline__ void make_lines_adjoint(const Phys<NI>& p, double lam
 #ifndef TSFF_FEXP
 #define TSFF_FEXP 1
 #endif
+// CLAMP = false: the caller guarantees a finite argument (ln f_e from the table or -50): no guard against -inf
+template <bool CLAMP = true>
 __device__ __forceinline__ double fexp(double x) {
 #if !TSFF_FEXP
   return exp(x);
 #endif
-  x = fmax(x, -800.0);
+  if (CLAMP) x = fmax(x, -800.0);
   const double n = __builtin_rint(x * 1.4426950408889634074);   // (not contractible: rint takes the product)
   double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
   r = __builtin_fma(n, -1.90821492927058770002e-10, r);
@@ -466,7 +474,7 @@ __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const
   b.xe = __builtin_fma(b.wd, b.ik, -L.Ud) * L.ivTe;        // :253
   double H;
   hermite_lookup_c(T, b.xe, H, b.dH);
-  b.F = fexp(H);                                           // :256
+  b.F = fexp<false>(H);                                    // :256
 }
 
 // ion terms of one species at normalised phase velocity xi (form_factor.py:243-249, 277-280):
@@ -485,6 +493,7 @@ __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& 
 #pragma clang fp contract(off)
   gs = fexp(-(xi * xi)) * kInvSqrt2Pi;
   const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
+  bool outf = false;
   if (ZH) {
     const double ax = fabs(xi);
     int i = (int)(ax * kXi2_ih);
@@ -499,14 +508,18 @@ __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& 
     zi = __hiloint2double(__double2hiint(zia) ^ sx, __double2loint(zia));
     dzr = __hiloint2double(__double2hiint(dzra) ^ sx, __double2loint(dzra));
   } else {
-    int i = (int)((xi - kXi2_0) * kXi2_ih);
-    i = i < 0 ? 0 : (i > kNXi2 - 2 ? kNXi2 - 2 : i);
-    const double t = (xi - __builtin_fma((double)i, kXi2_h, kXi2_0)) * kXi2_ih;
+    constexpr double kTop = (double)(kNXi2 - 1) * (1.0 - 1.1102230246251565e-16);
+    const double u = __builtin_fma(xi, kXi2_ih, -kXi2_0 * kXi2_ih);
+    const double uc = fmin(fmax(u, 0.0), kTop);
+    const double fl = __builtin_floor(uc);
+    const double t = uc - fl;
+    const int i = (int)fl;
     const double2 a = zp[i], b = zp[i + 1];
     const double dr = b.x - a.x, di = b.y - a.y;
     zr = __builtin_fma(t, dr, a.x); zi = __builtin_fma(t, di, a.y); dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
+    outf = u != uc;   // (outside the table <=> the clamp moved the position)
   }
-  const bool out = xi < kXi2_0 || xi > xlast;
+  const bool out = ZH ? (xi < kXi2_0 || xi > xlast) : outf;
   // straight-line form (selects instead of branches: one scheduling region per point; wavefront-uniform shortcuts for the
   // far EPW window and for the in-table IAW window were both measured slower)
   const double i2 = frcp(xi * xi);
@@ -519,8 +532,8 @@ __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& 
 // explicit FMAs, so that a spectrum comes out bit-identical from tsff_forward and from tsff_loss_grad whatever kernel runs.
 template <int NI>
 struct PointF {
-  double ik2, ike2, pike, vph, cre, cim, gsum, Wl, dW, idx, D, cer, cei, opc, er, ei, ieps2, ce2, ci2, N, t1, S, dop;
-  double xi[NI], zr[NI], zi[NI], dzr[NI], dzi[NI], iki2[NI], gs[NI];
+  double ik2, ike2, pike, vph, cim, gsum, Wl, dW, idx, D, cer, cei, opc, er, ei, ieps2, ce2, ci2, N, t1, S, dop;
+  double xi[NI], zr[NI], zi[NI], dzr[NI], dzi[NI], hk[NI], gs[NI];   // hk = -a_i / (2 k^2)
 };
 template <int NI, bool ZH>
 __device__ __forceinline__ void point_core(const Base& b, const Base& bn, bool has_next, const LineS<NI>& L, const Tables& T,
@@ -530,24 +543,24 @@ __device__ __forceinline__ void point_core(const Base& b, const Base& bn, bool h
   p.ike2 = L.a_e * p.ik2;
   p.pike = kPi * p.ike2;
   p.vph = b.wd * b.ik;
-  double cre = 0.0, cim = 0.0, gsum = 0.0;
+  double opc = 1.0, cim = 0.0, gsum = 0.0;   // opc = 1 + Re chi_i
 #pragma unroll
   for (int s = 0; s < NI; ++s) {
     p.xi[s] = p.vph * L.ixi[s];                              // :243
     ion_terms<ZH>(T.zp, p.xi[s], p.zr[s], p.zi[s], p.dzr[s], p.dzi[s], p.gs[s]);
-    p.iki2[s] = L.a_i[s] * p.ik2;
-    const double hk = -0.5 * p.iki2[s];
-    cre = __builtin_fma(hk, p.zr[s], cre);                   // :249
-    cim = __builtin_fma(hk, p.zi[s], cim);
-    gsum = __builtin_fma(L.cs[s], p.gs[s], gsum);            // :277-280
+    const double hk = L.hai[s] * p.ik2;
+    p.hk[s] = hk;
+    opc = __builtin_fma(hk, p.zr[s], opc);                   // :249
+    cim = s == 0 ? hk * p.zi[s] : __builtin_fma(hk, p.zi[s], cim);
+    gsum = s == 0 ? L.cs[s] * p.gs[s] : __builtin_fma(L.cs[s], p.gs[s], gsum);   // :277-280
   }
-  p.cre = cre; p.cim = cim; p.gsum = gsum;
+  p.cim = cim; p.gsum = gsum;
   w_lookup(T.W, b.xe, p.Wl, p.dW);
   p.idx = has_next ? frcp(bn.xe - b.xe) : 0.0;
   p.D = has_next ? (bn.F - b.F) * p.idx : 0.0;               // :258-259
   p.cer = -p.ike2 * p.Wl;                                    // :270-271
   p.cei = p.pike * p.D;                                      // :261
-  p.opc = 1.0 + cre;
+  p.opc = opc;
   p.er = p.opc + p.cer; p.ei = p.cei + cim;                  // :274
   const double eps2 = __builtin_fma(p.er, p.er, p.ei * p.ei);
   p.ieps2 = frcp(eps2);
@@ -592,7 +605,7 @@ __device__ __forceinline__ void point_reverse(const Base& b, const Base& bn, boo
   const double cer = pf.cer, cei = pf.cei, opc = pf.opc, cim = pf.cim, er = pf.er, ei = pf.ei, ieps2 = pf.ieps2, ce2 = pf.ce2, ci2 = pf.ci2;
   const double N = pf.N, t1 = pf.t1, S = pf.S, dop = pf.dop;
   const double* xi = pf.xi; const double* zr = pf.zr; const double* zi = pf.zi; const double* dzr = pf.dzr; const double* dzi = pf.dzi;
-  const double* iki2 = pf.iki2; const double* gs = pf.gs;
+  const double* hk = pf.hk; const double* gs = pf.gs;
   // ---- reverse ----
   // Accumulators with a DEFERRED wavefront-uniform factor (applied once per gradient point by lines_adjoint_finalize,
   // instead of once per point): LB.pref holds sum Sb S (x 1/pref), LB.i2wL holds sum PSQ wd (-> LB.wL, x -i2wL^2/2),
@@ -634,16 +647,16 @@ __device__ __forceinline__ void point_reverse(const Base& b, const Base& bn, boo
     const double v = u * gs[s];
     LB.cs[s] += v;
     const double w = creb * zr[s] + cimb * zi[s];
-    const double xib = -2.0 * (v * xi[s] * L.cs[s]) - 0.5 * iki2[s] * (creb * dzr[s] + cimb * dzi[s]);
+    const double xib = -2.0 * (v * xi[s] * L.cs[s]) + hk[s] * (creb * dzr[s] + cimb * dzi[s]);
     const double wk = w * ik2;
     LB.a_i[s] += wk;
-    k2acc += wk * iki2[s];
+    k2acc += wk * hk[s];
     vphb += xib * L.ixi[s];
     LB.ixi[s] += xib * vph;
   }
   const double we = ike2b * ik2;
   LB.a_e += we;
-  ba.k2 = 0.5 * k2acc - we * ike2;
+  ba.k2 = -k2acc - we * ike2;
   // v_ph = wd * ik
   ba.wd = PSQ * L.i2wL + vphb * b.ik;
   ba.ik = ikb0 + vphb * b.wd;
@@ -711,7 +724,7 @@ template <int NI>
 __device__ __forceinline__ void zero_lines(LineS<NI>& L) {
   L.wpe2 = L.wL = L.kL = L.ivTe = L.a_e = L.pref = L.Ud = L.Vd = L.i2wL = L.m = 0.0;
 #pragma unroll
-  for (int s = 0; s < NI; ++s) L.ixi[s] = L.a_i[s] = L.cs[s] = 0.0;
+  for (int s = 0; s < NI; ++s) L.ixi[s] = L.a_i[s] = L.cs[s] = L.hai[s] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
