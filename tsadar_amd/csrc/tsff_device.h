@@ -140,6 +140,7 @@ struct Tables {
   double* Hs;          // [nvx]  adjoint of the ln fe node slopes
   double vx0, dv, idv, vxlast;
   double u0, utop;     // -vx0 / dv and (nvx - 1)(1 - 2^-52): hermite_lookup_c's position in cell units and its clamp
+  const double* etab;  // [64] 2^(j/64) in LDS (fexp_t), or nullptr: polynomial exp
   int nvx;
 };
 __device__ __forceinline__ void tables_set_grid(Tables& T, double vx0, double dv, int nvx) {
@@ -450,6 +451,27 @@ __device__ __forceinline__ double fexp(double x) {
   return ldexp(p, (int)n);
 }
 
+// exp(x) for x <= ~1 with a 64-entry table: x = (64 n' + j) ln2/64 + r, |r| <= ln2/128, exp(x) = 2^n' 2^(j/64) exp(r) with a
+// degree-5 Taylor polynomial (truncation r^6/720 <= 3.5e-17) -- 15 VALU instructions and one LDS read where the
+// degree-13 polynomial of fexp takes 20 (two exps per (lambda, theta) point: ln f_e -> f_e and exp(-xi_i^2)).  tab[j] = 2^(j/64)
+// correctly rounded (host); total error ~1.5 ulp.
+constexpr int kNExpTab = 64;
+template <bool CLAMP = true>
+__device__ __forceinline__ double fexp_t(double x, const double* __restrict__ tab) {
+  if (CLAMP) x = fmax(x, -800.0);
+  const double n = __builtin_rint(x * 92.332482616893656908);          // 64 / ln 2
+  double r = __builtin_fma(n, -0.01083042469326756, x);           // ln2/64, high part (trailing zeros: n * hi exact)
+  r = __builtin_fma(n, -2.9815858269852933e-12, r);              // low part
+  double p = 8.333333333333333e-03;                                    // 1/5!
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  const int ni = (int)n;
+  return ldexp(p * tab[ni & (kNExpTab - 1)], ni >> 6);
+}
+
 struct Base {  // quantities needed at point j AND as the right neighbour of point j-1
   double ks, k2, ik, wd, xe, F, dH;   // k = k2*ik, v_ph = wd*ik
 };
@@ -474,7 +496,7 @@ __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const
   b.xe = __builtin_fma(b.wd, b.ik, -L.Ud) * L.ivTe;        // :253
   double H;
   hermite_lookup_c(T, b.xe, H, b.dH);
-  b.F = fexp<false>(H);                                    // :256
+  b.F = T.etab ? fexp_t<false>(H, T.etab) : fexp<false>(H);   // :256  (T.etab is set or not per kernel: folded at compile time)
 }
 
 // ion terms of one species at normalised phase velocity xi (form_factor.py:243-249, 277-280):
@@ -489,9 +511,9 @@ __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const
 constexpr int kNZh = kNXi2 / 2 + 1;
 template <bool ZH = true>
 __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& zr, double& zi, double& dzr,
-                                          double& dzi, double& gs) {
+                                          double& dzi, double& gs, const double* etab = nullptr) {
 #pragma clang fp contract(off)
-  gs = fexp(-(xi * xi)) * kInvSqrt2Pi;
+  gs = (etab ? fexp_t(-(xi * xi), etab) : fexp(-(xi * xi))) * kInvSqrt2Pi;
   const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
   bool outf = false;
   if (ZH) {
@@ -547,7 +569,7 @@ __device__ __forceinline__ void point_core(const Base& b, const Base& bn, bool h
 #pragma unroll
   for (int s = 0; s < NI; ++s) {
     p.xi[s] = p.vph * L.ixi[s];                              // :243
-    ion_terms<ZH>(T.zp, p.xi[s], p.zr[s], p.zi[s], p.dzr[s], p.dzi[s], p.gs[s]);
+    ion_terms<ZH>(T.zp, p.xi[s], p.zr[s], p.zi[s], p.dzr[s], p.dzi[s], p.gs[s], T.etab);
     const double hk = L.hai[s] * p.ik2;
     p.hk[s] = hk;
     opc = __builtin_fma(hk, p.zr[s], opc);                   // :249

@@ -30,6 +30,7 @@ struct KStatic {
   const double2* zpf;        // [1640] the full table (spectrum kernels, when LDS allows)
   const double* xi1;         // [1024]
   const double* xi2;         // [1640]
+  const double* etab;        // [64] 2^(j/64), the table of fexp_t
   const double* taps[2];
   int ntaps[2];              // length of the bin-averaged IRF taps hb
   int toff[2];               // ybin[p] = sum_s hb[s] x[p * ppp + toff + s]
