@@ -1810,3 +1810,53 @@ def test_loss_grad_packed_layout(torch_mod):
     eng.set_launch_plan(0)
     with pytest.raises(L.TsffError, match="packed-output"):
         eng.loss_grad_packed(X, batch, w, gm, act, Bg, Bg - 2)   # columns past the end of the global batch
+
+
+@pytest.mark.parametrize("kind", ["epw", "iaw"])
+def test_dispersion_known_answers_through_the_hip_path(torch_mod, kind):
+    """The reference's two known-answer tests (tests/test_form_factor/test_epw.py:33-74: EPW peaks vs Bohm-Gross
+    omega^2 = wpe^2 + 3 k^2 vTe^2; test_iaw.py:40-71: IAW peaks vs omega = 2 kL sqrt((Z Te + 3 Ti)/Mi); rtol 1e-2 both) on
+    the spectrum the HIP path computes (tsff_form_factor, theta = 60 degrees, 4096 wavelengths), and the same spectrum against
+    the oracle's."""
+    from scipy.signal import find_peaks
+
+    cfg = decks.deck_kat(kind)
+    cfg["other"]["points_per_pixel"] = 4
+    cfg["data"]["fit_rng"].update(forward_epw_start=400.0, forward_epw_end=700.0, forward_iaw_start=525.0, forward_iaw_end=528.0)
+    cfg["other"]["extraoptions"]["load_ion_spec"] = True
+    cfg = decks.finish(cfg)
+    sa = dict(sa=np.array([60.0]), weights=np.ones((1, 1)))
+    eng = _engine(cfg, sa, activate=False)
+    P_ = cfg["parameters"]
+    phys = {k: np.array([v]) for k, v in dict(Te=P_["electron"]["Te"]["val"], ne=P_["electron"]["ne"]["val"], m=2.0, lam=P_["general"]["lam"]["val"],
+                                               amp1=1.0, amp2=1.0, amp3=1.0, ne_gradient=0.0, Te_gradient=0.0, ud=0.0, Va=0.0,
+                                               Ti_1=P_["ion-1"]["Ti"]["val"], Z_1=P_["ion-1"]["Z"]["val"], A_1=P_["ion-1"]["A"]["val"], fract_1=1.0).items()}
+    X = util.normed_to_matrix(phys, 1)
+    feature, rng = (0, [400.0, 700.0]) if kind == "epw" else (1, [525.0, 528.0])
+    npts = cfg["other"]["npts"]
+    spec = eng.form_factor(feature, X).cpu().numpy()[0, 0, :, 0]
+    p = orc.lineout_params(phys, 0, 1)
+    Po, lam_cm = orc.form_factor(rng, npts, 0.0, sa["sa"], 1, p, orc.velocity_grid(128), orc.dlm_fe(2.0, 128))
+    assert np.max(np.abs(spec - np.squeeze(Po)) / np.abs(np.squeeze(Po))) < 1e-7
+    lam_cm = np.squeeze(lam_cm)
+    omgpe = orc.C0 * np.sqrt(p["ne"] * 1e20)
+    omgL = 2 * np.pi * 1e7 * orc.C / p["lam"]
+    kL = np.sqrt(omgL**2 - omgpe**2) / orc.C
+    if kind == "epw":
+        peaks, props = find_peaks(spec, height=(0.01, 0.5), prominence=0.02)
+        hi = peaks[np.argmax(props["peak_heights"])]
+        lo = peaks[np.argsort(props["peak_heights"])[0]]
+        model = 2 * np.pi * orc.C / lam_cm[[hi, lo]]
+        ks = np.sqrt(model**2 - omgpe**2) / orc.C
+        k = np.sqrt(ks**2 + kL**2 - 2 * ks * kL * np.cos(60 * np.pi / 180))
+        omg = np.sqrt(omgpe**2 + 3 * k**2 * (p["Te"] / orc.ME))
+        np.testing.assert_allclose(model, [omgL + omg[0], omgL - omg[1]], rtol=1e-2)
+    else:
+        peaks, props = find_peaks(spec, height=0.1, prominence=0.2)
+        hi = peaks[np.argmax(props["peak_heights"])]
+        second = peaks[np.argpartition(props["peak_heights"], -2)[-2]]
+        model = 2 * np.pi * orc.C / lam_cm[[hi, second]]
+        omg = 2 * kL * np.sqrt((0.5 + 3 * 0.2) / orc.MP)
+        np.testing.assert_allclose(sorted([omgL + omg, omgL - omg]), sorted(model), rtol=1e-2)
+        cs = np.sqrt((p["Z"][0] * p["Te"] + 3 * p["Ti"][0]) / (p["A"][0] * orc.MP))
+        assert abs(abs(model[0] - model[1]) / (2 * kL * cs) - 1) < 0.1
