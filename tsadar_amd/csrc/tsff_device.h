@@ -616,12 +616,28 @@ __device__ __forceinline__ void point_core(const Base& b, const Base& bn, bool h
 }
 // point_forward_sd: S (1 + 2 w/w_L) -- everything but the factor pref ws^2, which k_spectrum applies once per angle
 // (pref) and once per wavelength sample (ws^2) instead of once per point
-template <int NI, bool ZH = true>
+template <int NI, bool ZH = true, bool FAR = false>
 __device__ __forceinline__ double point_forward_sd(const Base& b, const Base& bn, bool has_next, const LineS<NI>& L,
                                                    const Tables& T) {
   PointF<NI> p;
-  point_core<NI, ZH>(b, bn, has_next, L, T, p);
+  point_core<NI, ZH, FAR>(b, bn, has_next, L, T, p);
   return p.S * p.dop;
+}
+
+// Is |xi_i| > kXiFar (with 2 % margin) guaranteed at every point of the samples [jw0, jw1] (all angles, all species)?
+//   |xi_i| = |w - k V| / k * ixi >= (min |w| - kmax |V|) / kmax * ixi,   kmax = k_s,max + k_L  (triangle inequality),
+// w = ws - wL of one sign over the range (ws and k_s fall monotonically with the sample index).  Evaluated with
+// wavefront-uniform arguments; the result is made a scalar.
+template <int NI>
+__device__ __forceinline__ bool far_range(const double* __restrict__ omgs, int jw0, int jw1, const LineS<NI>& L) {
+  const double w0 = omgs[jw0], w1 = omgs[jw1];
+  const double d0 = w0 - L.wL, d1 = w1 - L.wL;
+  const double kmax = ks_eval(w0, L.wpe2) + L.kL;
+  const double dmin = fmin(fabs(d0), fabs(d1)) - kmax * fabs(L.Vd);
+  bool ok = (d0 > 0.0) == (d1 > 0.0) && d0 != 0.0 && d1 != 0.0;
+#pragma unroll
+  for (int s = 0; s < NI; ++s) ok = ok && dmin * L.ixi[s] > (kXiFar * 1.02) * kmax;
+  return __builtin_amdgcn_readfirstlane((int)ok) != 0;
 }
 template <int NI>
 __device__ __forceinline__ double point_forward(double ws, const Base& b, const Base& bn, bool has_next,
