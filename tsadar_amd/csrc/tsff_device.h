@@ -653,13 +653,13 @@ struct BaseAdj {  // adjoints flowing into base quantities of a point
 // of the right neighbour's (xe, F) (xen, Fn), and accumulate lineout-scalar adjoints into LB.
 // GM: 0 plasma parameters only, 1 + DLM order m (tangent tables), 2 + the distribution-function tables themselves
 // PQ = Pbar pref ws^2 (the seed times the factor point_forward_sd leaves out)
-template <int NI, int GM = 0, bool ZH = true>
+template <int NI, int GM = 0, bool ZH = true, bool FAR = false>
 __device__ __forceinline__ void point_reverse(const Base& b, const Base& bn, bool has_next,
                                               const LineS<NI>& L, const Tables& T, double PQ,
                                               BaseAdj& ba, double& xen, double& Fn, LineS<NI>& LB, FeAcc& fa) {
   // ---- recompute forward ----
   PointF<NI> pf;
-  point_core<NI, ZH>(b, bn, has_next, L, T, pf);
+  point_core<NI, ZH, FAR>(b, bn, has_next, L, T, pf);
   const double ik2 = pf.ik2, ike2 = pf.ike2, vph = pf.vph, gsum = pf.gsum, Wl = pf.Wl, dW = pf.dW, idx = pf.idx, D = pf.D;
   const double cer = pf.cer, cei = pf.cei, opc = pf.opc, cim = pf.cim, er = pf.er, ei = pf.ei, ieps2 = pf.ieps2, ce2 = pf.ce2, ci2 = pf.ci2;
   const double N = pf.N, t1 = pf.t1, S = pf.S, dop = pf.dop;
@@ -680,10 +680,14 @@ __device__ __forceinline__ void point_reverse(const Base& b, const Base& bn, boo
   const double ci2b2 = 2.0 * (NbI * b.F);       // 2 x adjoint of |1 + chi_i|^2
   ba.F = NbI * ci2;
   LB.ivTe += (Nb * ci2) * b.F;
-  const double ce2b2 = 2.0 * (Nb * gsum);       // 2 x adjoint of |chi_e|^2
   const double erb = e2 * er, eib = e2 * ei;
-  const double cerb = erb + ce2b2 * cer, ceib = eib + ce2b2 * cei;
-  const double creb = erb + ci2b2 * opc, cimb = eib + ci2b2 * cim;
+  double cerb = erb, ceib = eib, cimb = eib;
+  if (!FAR) {   // (FAR: the ion numerator gsum and Im chi_i vanish identically, see point_core)
+    const double ce2b2 = 2.0 * (Nb * gsum);     // 2 x adjoint of |chi_e|^2
+    cerb = erb + ce2b2 * cer; ceib = eib + ce2b2 * cei;
+    cimb = eib + ci2b2 * cim;
+  }
+  const double creb = erb + ci2b2 * opc;
   const double cp = ceib * kPi;
   const double ike2b = cp * D - cerb * Wl;
   const double Wlb = -cerb * ike2;  // adjoint of the interpolated W
@@ -700,13 +704,19 @@ __device__ __forceinline__ void point_reverse(const Base& b, const Base& bn, boo
   xen = -Fn * D;
   ba.xe -= xen;
   double k2acc = 0.0, vphb = 0.0;
-  const double u = Nb * ce2;
+  const double u = FAR ? 0.0 : Nb * ce2;
 #pragma unroll
   for (int s = 0; s < NI; ++s) {
-    const double v = u * gs[s];
-    LB.cs[s] += v;
-    const double w = creb * zr[s] + cimb * zi[s];
-    const double xib = -2.0 * (v * xi[s] * L.cs[s]) + hk[s] * (creb * dzr[s] + cimb * dzi[s]);
+    double w, xib;
+    if (FAR) {   // gs = Im Z' = d Im Z' = 0
+      w = creb * zr[s];
+      xib = hk[s] * (creb * dzr[s]);
+    } else {
+      const double v = u * gs[s];
+      LB.cs[s] += v;
+      w = creb * zr[s] + cimb * zi[s];
+      xib = -2.0 * (v * xi[s] * L.cs[s]) + hk[s] * (creb * dzr[s] + cimb * dzi[s]);
+    }
     const double wk = w * ik2;
     LB.a_i[s] += wk;
     k2acc += wk * hk[s];
