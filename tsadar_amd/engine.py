@@ -609,7 +609,7 @@ class Engine:
     def set_launch_plan(self, plan: int):
         """Bit mask (TSFF_OPT_LAUNCH_PLAN).  0: automatic (one 256-thread workgroup per (lineout, feature) when two fit a
         CU; loss + gradient by the one-sweep kernel where its restrictions hold); bit 0: never interleave the features;
-        bit 1: always the two-sweep kernel."""
+        bit 1: always the two-sweep kernel; bit 2: never three forward-only workgroups per CU."""
         L.check(self.lib, self.h, self.lib.tsff_set_option(self.h, L.OPT_LAUNCH_PLAN, int(plan)))
 
     def fp64_fma_peak_tflops(self) -> float:
