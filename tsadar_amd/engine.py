@@ -485,8 +485,9 @@ class Engine:
         ia = self._vec(i_amps, B) if self.load_ion else None
         ne_, ni_ = self._mat(noise_e, B), self._mat(noise_i, B)
         fe_d = self.dev(fe)
-        E = torch.zeros((B, L.NBINS), dtype=torch.float64, device=self.device)
-        I = torch.zeros((B, L.NBINS), dtype=torch.float64, device=self.device)
+        # (the kernel writes every entry of a loaded feature; a feature that is not loaded comes back as zeros)
+        E = (torch.empty if self.load_ele else torch.zeros)((B, L.NBINS), dtype=torch.float64, device=self.device)
+        I = (torch.empty if self.load_ion else torch.zeros)((B, L.NBINS), dtype=torch.float64, device=self.device)
         self._sync_stream()
         rc = self.lib.tsff_forward(self.h, self._ptr(X), self._ptr(fe_d), self._ptr(ea), self._ptr(ia), self._ptr(ne_),
                                    self._ptr(ni_), B, self._ptr(E), self._ptr(I))
