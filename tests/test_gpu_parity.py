@@ -555,6 +555,11 @@ def _dist_rank(rank, world, port, out):
     tpl.X[:] = tp.X[lo:hi]
     value, flat = lf.vg_loss(x0, tree.StaticParams(tpl), local)
     np.save(os.path.join(out, f"r{rank}.npy"), np.concatenate([[value], flat]))
+    if rank == 0:   # the same step on one rank, same process, same device
+        single = LossFunction(cfg, util.sa_fit(B), full)
+        single.unravel_weights = lf.unravel_weights
+        v1, g1 = single.vg_loss(x0, tree.StaticParams(tp), full)
+        np.save(os.path.join(out, "single.npy"), np.concatenate([[v1], g1]))
     dist.destroy_process_group()
 
 
@@ -572,6 +577,11 @@ def test_two_rank_sharded_fit_step_on_gpu(torch_mod, tmp_path):
     mp.spawn(_dist_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
     np.testing.assert_array_equal(r0, r1)
+    # 1 rank == 2 ranks: a lineout's gradient is reduced inside its own workgroups in a fixed order and the all-reduce only adds
+    # zeros to it (bit-identical); the three loss sums are folded per shard first (1e-14)
+    one = np.load(tmp_path / "single.npy")
+    np.testing.assert_array_equal(r0[1:], one[1:])
+    assert abs(r0[0] - one[0]) <= 1e-14 * abs(one[0])
     z = np.load("tests/golden/oracle_fit_b4.npz")
     gref = z["grad"][:, [0, 1, 2, 4, 5, 3]].T.reshape(-1)
     assert abs(r0[0] - float(z["loss"])) < 1e-9 * abs(float(z["loss"]))
