@@ -161,14 +161,17 @@ def config4_main(args):
         "roofline": {"bound": "lds" if arts else "l1", "achieved": stencil_bytes / kavg_s / 1e12, "peak": lds_peak if arts else l1_peak, "unit": "TB/s",
                      "frac": stencil_bytes / kavg_s / 1e12 / (lds_peak if arts else l1_peak), "traffic": None,
                      "kernel": "k_form_factor_2d<1,true,4,false> (table in LDS, one ds_read_b64 per stencil entry)" if arts else
-                               "k_form_factor_2d<1,false,1,false> (table read through L1/L2 from the padded copy of k_pad2d)",
+                               "k_form_factor_2d<1,false,1,false> (table read through L1/L2 from the padded copy of k_pad2d and its transpose; rolling 4x4 window)",
                      "kernel_avg_ms": kavg_s * 1e3, "kernel_median_ms": float(np.median(kt)),
                      "algorithmic_bytes_per_launch": stencil_bytes,
                      "note": ("achieved = 128 B of stencil per bicubic sample x samples / kernel time; peak = 256 B per clock and CU of ds_read_b64 x 256 CUs x "
                               "2.4 GHz (conflict-free; the sampler's rotated lines measure 2.0 passes per read); the kernel issues 75 VALU instructions per "
                               "sample and is VALU-issue bound first (fp64_valu)") if arts else
                              ("achieved = 128 B of stencil per bicubic sample x samples / kernel time; peak = vector-L1 read rate measured on "
-                              "this device by tsff_l1_read_peak (16-byte loads from a 16 KB window); HBM traffic is the 532 KB table + 4 MB of P"),
+                              "this device by tsff_l1_read_peak (16-byte loads from a 16 KB window); HBM traffic is the 532 KB table + 4 MB of P. "
+                              "Since round 2 the sampler keeps the stencil in a rolling register window and REQUESTS 64 B per sample (the entering "
+                              "row and column): requested = achieved / 2; it is VALU-issue bound (121 instructions per sample, SQ busy 0.87)"),
+                     "requested_tbps": None if arts else stencil_bytes / 2 / kavg_s / 1e12,
                      "fp64_valu": {"achieved_tflops": flop / kavg_s / 1e12, "peak": FP64_PEAK / 1e12, "frac": flop / kavg_s / FP64_PEAK,
                                    "flop_per_sample": 60.0}},
     }

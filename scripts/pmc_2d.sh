@@ -7,7 +7,8 @@ python3 - "$tag" <<'PY'
 import csv, collections, glob, json, sys
 tag = sys.argv[1]
 out = {"note": "rocprofv3 --pmc, two passes over scripts/time_2d.py; averages over the launches of each kernel (counters summed over the device)", "kernels": {}}
-for kern in ("k_form_factor_2d<1, true, 4, false>", "k_form_factor_2d<1, true, 4, true>", "k_form_factor_2d<1, false, 1, false>"):
+for kern in ("k_form_factor_2d<1, true, 4, false>", "k_form_factor_2d<1, true, 4, true>", "k_form_factor_2d<1, false, 1, false>", "k_form_factor_2d<1, false, 1, true>",
+             "k_form_factor_2d_adj<1, false, 1>", "k_form_factor_2d_adj<1, true, 4>", "k_ff2d_table_adj"):
     c = {}
     for d in ("gpurun_out/pmc_2d_a", "gpurun_out/pmc_2d_b"):
         for f in glob.glob(d + "/*/*counter_collection.csv"):
