@@ -1296,6 +1296,63 @@ def test_launch_plans_agree(torch_mod):
         assert np.max(np.abs(g5[:, s] - gref[:, s])) < 1e-6 * np.max(np.abs(gref[:, s])), s
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_one_sweep_kernel_random_geometry(torch_mod, seed):
+    """k_spectrum_fused on randomly drawn geometry: 3 to 24 scattering angles (the base-point exchange between lanes is taken
+    up to 16 angles, the plain form above), EPW windows that contain the laser line, end beside it or lie wholly on one side (all
+    128-sample units asymptotic / none), IAW windows of different width, cold and hot ions (|xi_i| on both sides of the 28 that
+    switches the asymptotic ion terms), one or two species, drifts.  Against the two-sweep kernel (spectra and loss sums the
+    same bits, gradient 1e-11) and against the C++ oracle (spectra 1e-8, gradient 1e-6)."""
+    from oracle import c_oracle as co
+
+    rng = np.random.default_rng(7000 + seed)
+    n_ion = 1 + seed % 2
+    cfg = decks.deck_fit(active=("Te", "ne", "Ti", "Va", "lam", "amp1", "amp2", "amp3", "ud"), n_ion=n_ion)
+    other = cfg["other"]
+    lo = float(rng.choice([400.0, 450.0, 500.0, 528.5, 540.0]))
+    hi = float(rng.choice([520.0, 526.0, 560.0, 700.0])) if lo < 520.0 else float(rng.choice([600.0, 700.0]))
+    other["lamrangE"] = [lo, hi]
+    c = float(rng.uniform(526.0, 527.0))
+    hw = float(rng.choice([0.4, 0.75, 2.5]))
+    other["lamrangI"] = [c - hw, c + hw]
+    other["PhysParams"]["widIRF"] = {"spect_stddev_ele": float(rng.uniform(0.5, 2.0)) * (hi - lo) / 300.0,
+                                     "spect_stddev_ion": float(rng.uniform(0.008, 0.03)) * hw / 0.75}
+    r = cfg["data"]["fit_rng"]
+    r["blue_min"], r["blue_max"] = lo + 0.1 * (hi - lo), lo + 0.45 * (hi - lo)
+    r["red_min"], r["red_max"] = lo + 0.55 * (hi - lo), lo + 0.9 * (hi - lo)
+    r["iaw_min"], r["iaw_max"] = c - 0.8 * hw, c + 0.8 * hw
+    r["iaw_cf_min"], r["iaw_cf_max"] = c - 0.05 * hw, c + 0.05 * hw
+    cfg = decks.finish(cfg)
+    B = 3
+    na = int(rng.integers(3, 25))
+    ang = np.sort(rng.uniform(20.0, 150.0, na))
+    wts = rng.uniform(0.2, 1.0, na)
+    sa = dict(sa=ang, weights=(wts / wts.sum()) * np.ones([B, na]))
+    batch = util.synthetic_batch(cfg, sa, B, seed=7100 + seed)
+    normed = util.random_lineouts(cfg, B, seed=7200 + seed, ranges=dict(ud=(-2, 2), Va=(-4, 4), Ti_1=(0.012, 0.9), Ti_2=(0.012, 0.9), Te=(0.05, 1.4)))
+    i_norm, e_norm = orc.loss_norms(cfg, batch)
+    eng = _engine(cfg, sa)
+    X = util.normed_to_matrix(normed, n_ion)
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    gm = eng.slots.active.astype(np.uint8)
+    out = {}
+    for plan in (0, 8, 2):   # one-sweep (exchange where it applies), one-sweep without the exchange, two-sweep
+        eng.set_launch_plan(plan)
+        out[plan] = [a.cpu().numpy() for a in eng.loss_grad(X, batch, w, gm, want_spectra=True)]
+    eng.set_launch_plan(0)
+    assert np.isfinite(out[0][1]).all() and np.isfinite(out[0][2]).all()
+    for plan in (8, 2):
+        for k in (0, 2, 3):
+            np.testing.assert_array_equal(out[0][k], out[plan][k])
+        np.testing.assert_allclose(out[0][1], out[plan][1], rtol=1e-11, atol=1e-14 * np.abs(out[0][1]).max())
+    np.testing.assert_array_equal(out[0][1], out[8][1])   # the exchanged base points are the ones the lane would have computed
+    sums, gref, Eo, Io = co.loss_grad(cfg, sa, X, batch, w=w, gmask=gm)
+    assert util.rel_err(out[0][2], Eo) < 1e-8 and util.rel_err(out[0][3], Io) < 1e-7, (lo, hi, na)
+    np.testing.assert_allclose(out[0][0], sums.sum(axis=0), rtol=1e-9)
+    for sl in np.nonzero(gm)[0]:
+        assert np.max(np.abs(out[0][1][:, sl] - gref[:, sl])) <= 1e-6 * np.max(np.abs(gref)) , (sl, lo, hi, na)
+
+
 @pytest.mark.parametrize("ccd,n_lam,start,end", [((1024, 1024), 1024, 90, 950), ((128, 256), 256, 10, 110)])
 def test_ats_adjoint_directional_derivatives(torch_mod, ccd, n_lam, start, end):
     """Reverse of the ARTS instrument chain (tsff_ats_adjoint): for a random linear functional <Ebar, ThryE(P)> the

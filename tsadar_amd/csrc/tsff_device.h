@@ -484,13 +484,20 @@ __device__ __forceinline__ double ks_eval(double ws, double wpe2) {
   return s * (1.0 / kC);
 }
 
+// k^2 = k_s^2 + k_L^2 - 2 k_s k_L cos(theta) (form_factor.py:220), in the one rounding sequence every kernel uses
+template <int NI>
+__device__ __forceinline__ double base_k2(double ks, double ct, const LineS<NI>& L) {
+#pragma clang fp contract(off)
+  const double c1 = (2.0 * L.kL) * ct, c0 = L.kL * L.kL;   // wavefront-uniform: hoisted out of the strip loops
+  return __builtin_fma(ks, ks - c1, c0);
+}
+
 template <int NI>
 __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const LineS<NI>& L, const Tables& T,
                                           Base& b) {
 #pragma clang fp contract(off)
   b.ks = ks;
-  const double c1 = (2.0 * L.kL) * ct, c0 = L.kL * L.kL;   // wavefront-uniform: hoisted out of the strip loops
-  b.k2 = __builtin_fma(ks, ks - c1, c0);                   // :220  k_s^2 + k_L^2 - 2 k_s k_L cos(theta)
+  b.k2 = base_k2<NI>(ks, ct, L);
   double k;
   fsqrt2(b.k2, k, b.ik);
   b.wd = __builtin_fma(-k, L.Vd, ws - L.wL);               // :216, 222-223
@@ -504,32 +511,39 @@ __device__ __forceinline__ void base_eval(double ws, double ks, double ct, const
 // Z'(xi) = jnp.interp(xi, xi2, Zp, left=xi**-2 / 0, right=xi**-2 / 0) with its slope, and
 // gs = exp(-xi^2)/sqrt(2 pi).
 // The table is held for xi >= 0 only (kNZh = 821 nodes 0, 0.01, ..., 8.2): the shipped rdWT / idWT data are exactly even
-// (Re Z') and odd (Im Z') -- tsff_create verifies it -- so Z'(xi) = (Re Z'(|xi|), sign(xi) Im Z'(|xi|)) and the slopes
-// pick up the opposite parity.  The table's own domain stays the reference's asymmetric [-8.2, 8.19] (arange): outside
+// (Re Z') and odd (Im Z') -- tsff_create verifies it -- so node i of the full table is node |i - 820| of the half table with
+// the sign of i - 820 on the odd part.  The table's own domain stays the reference's asymmetric [-8.2, 8.19] (arange): outside
 // it the asymptote applies.  13 KB of LDS per workgroup less than the full table.
-// ZH = false: the full 1640-node table (no sign handling: about 1 % fewer instructions per point); the spectrum kernels
-// use it whenever the LDS budget does not need the 13 KB back (launch_spectrum decides).
+// ZH = false: the full 1640-node table (no index mirror, no sign handling: about 1 % fewer instructions per point); the
+// spectrum kernels use it whenever the LDS budget does not need the 13 KB back (launch_spectrum decides).  Both forms
+// interpolate between the same two node values with the same weight in the same order: a spectrum does not depend on which
+// one the launch plan picked (test_one_sweep_kernel_random_geometry caught an earlier half-table form that interpolated from
+// the other end for xi < 0: 1e-16 per lookup, visible in the last bits when two plans of one deck differed in ZH).
 constexpr int kNZh = kNXi2 / 2 + 1;
 template <bool ZH = true>
 __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& zr, double& zi, double& dzr,
                                           double& dzi, double& gs, const double* etab = nullptr) {
 #pragma clang fp contract(off)
   gs = (etab ? fexp_t(-(xi * xi), etab) : fexp(-(xi * xi))) * kInvSqrt2Pi;
-  const double xlast = kXi2_0 + (kNXi2 - 1) * kXi2_h;
   bool outf = false;
   if (ZH) {
-    const double ax = fabs(xi);
-    int i = (int)(ax * kXi2_ih);
-    i = i > kNZh - 2 ? kNZh - 2 : i;
-    const double t = __builtin_fma(-(double)i, kXi2_h, ax) * kXi2_ih;
-    const double2 a = zp[i], b = zp[i + 1];
+    // the cell and the weight exactly as the full table takes them (below), then the two nodes through the mirror: node i of the
+    // full table, xi2[i] = -8.2 + 0.01 i, is node |i - 820| of the half table with the sign of i - 820 on the odd part.  The
+    // interpolation runs over the same two values in the same order: the same bits as ZH = false.
+    constexpr double kTop = (double)(kNXi2 - 1) * (1.0 - 1.1102230246251565e-16);
+    constexpr int kMid = kNZh - 1;   // full-table index of xi = 0
+    const double u = __builtin_fma(xi, kXi2_ih, -kXi2_0 * kXi2_ih);
+    const double uc = fmin(fmax(u, 0.0), kTop);
+    const double fl = __builtin_floor(uc);
+    const double t = uc - fl;
+    const int i = (int)fl, da = i - kMid, db = da + 1;
+    double2 a = zp[da < 0 ? -da : da], b = zp[db < 0 ? -db : db];
+    const int sx = da & (int)0x80000000;   // (node i + 1 = 0 when da = -1: its odd part is an exact zero, the sign is immaterial)
+    a.y = __hiloint2double(__double2hiint(a.y) ^ sx, __double2loint(a.y));
+    b.y = __hiloint2double(__double2hiint(b.y) ^ sx, __double2loint(b.y));
     const double dr = b.x - a.x, di = b.y - a.y;
-    // odd parts take the sign of xi: one AND and two XORs on the high words instead of compare + selects
-    const int sx = __double2hiint(xi) & (int)0x80000000;
-    const double zia = __builtin_fma(t, di, a.y), dzra = dr * kXi2_ih;
-    zr = __builtin_fma(t, dr, a.x); dzi = di * kXi2_ih;
-    zi = __hiloint2double(__double2hiint(zia) ^ sx, __double2loint(zia));
-    dzr = __hiloint2double(__double2hiint(dzra) ^ sx, __double2loint(dzra));
+    zr = __builtin_fma(t, dr, a.x); zi = __builtin_fma(t, di, a.y); dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
+    outf = u != uc;
   } else {
     constexpr double kTop = (double)(kNXi2 - 1) * (1.0 - 1.1102230246251565e-16);
     const double u = __builtin_fma(xi, kXi2_ih, -kXi2_0 * kXi2_ih);
@@ -542,7 +556,7 @@ __device__ __forceinline__ void ion_terms(const double2* zp, double xi, double& 
     zr = __builtin_fma(t, dr, a.x); zi = __builtin_fma(t, di, a.y); dzr = dr * kXi2_ih; dzi = di * kXi2_ih;
     outf = u != uc;   // (outside the table <=> the clamp moved the position)
   }
-  const bool out = ZH ? (xi < kXi2_0 || xi > xlast) : outf;
+  const bool out = outf;
   // straight-line form (selects instead of branches: one scheduling region per point; wavefront-uniform shortcuts for the
   // far EPW window and for the in-table IAW window were both measured slower)
   const double i2 = frcp(xi * xi);
