@@ -1050,8 +1050,13 @@ def test_random_decks_forward_loss_gradient(torch_mod, seed):
     cfg, n_ion = _random_deck(seed)
     B = 2
     sa = util.sa_fit(B)
-    batch = util.synthetic_batch(cfg, sa, B, seed=300 + seed)
     rng = np.random.default_rng(seed)
+    if seed >= 5:   # not the P9 fibre bundle: a random set of scattering angles and weights
+        na = int(np.random.default_rng(900 + seed).integers(3, 15))
+        ang = np.sort(np.random.default_rng(901 + seed).uniform(25.0, 140.0, na))
+        wts = np.random.default_rng(902 + seed).uniform(0.2, 1.0, na)
+        sa = dict(sa=ang, weights=(wts / wts.sum()) * np.ones([B, na]))
+    batch = util.synthetic_batch(cfg, sa, B, seed=300 + seed)
     batch["noise_e"] = 0.02 * rng.random((B, 1024))
     batch["noise_i"] = 0.02 * rng.random((B, 1024))
     normed = util.random_lineouts(cfg, B, seed=400 + seed, ranges=dict(ud=(-2, 2), Ti_2=(0.05, 0.5)))
