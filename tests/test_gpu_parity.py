@@ -1301,6 +1301,45 @@ def test_launch_plans_agree(torch_mod):
         assert np.max(np.abs(g5[:, s] - gref[:, s])) < 1e-6 * np.max(np.abs(gref[:, s])), s
 
 
+@pytest.mark.parametrize("ppp,n_ion,active", [(5, 1, ("Te", "ne", "Ti", "Va", "lam", "amp1")), (2, 2, ("Te", "ne", "Ti", "Z", "Va", "ud", "lam", "amp1", "amp2", "amp3")),
+                                              (3, 1, ("Te", "ne", "m", "amp1", "amp2", "lam"))])
+def test_rows_kernel_points_per_pixel(torch_mod, ppp, n_ion, active):
+    """k_spectrum_rows (points_per_pixel > 1: the one-sweep kernel with its Jacobian rows in a global scratch array) against
+    the two-sweep kernel on the same deck -- spectra and loss sums the same bits, gradient to 1e-11 -- and against the C++
+    oracle; 5 points per pixel is the reference's default deck shape (tests/configs/1d-defaults.yaml:100); the third case
+    fits the DLM order per lineout (tangent tables, GM = 1)."""
+    from oracle import c_oracle as co
+
+    dlm = "m" in active
+    cfg = decks.deck_fit(points_per_pixel=ppp, active=active, n_ion=n_ion, m=2.6 if dlm else 2.0)
+    B = 3
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B, seed=500 + ppp)
+    rng = np.random.default_rng(510 + ppp)
+    batch["noise_e"] = 0.02 * rng.random((B, 1024))
+    batch["noise_i"] = 0.02 * rng.random((B, 1024))
+    eng = _engine(cfg, sa)
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    X = util.normed_to_matrix(normed, n_ion)
+    gm = eng.slots.active.astype(np.uint8)
+    out = {}
+    for plan in (0, 2):
+        eng.set_launch_plan(plan)
+        out[plan] = [a.cpu().numpy() for a in eng.loss_grad(X, batch, w, gm, want_spectra=True)]
+    eng.set_launch_plan(0)
+    for k in (2, 3):
+        np.testing.assert_array_equal(out[0][k], out[2][k])
+    # (the loss sums are folded over 256 threads x 4 bins here, over 512 x 2 by the two-sweep kernel's one-feature workgroups)
+    np.testing.assert_allclose(out[0][0], out[2][0], rtol=1e-14)
+    np.testing.assert_allclose(out[0][1], out[2][1], rtol=1e-10, atol=1e-12 * np.abs(out[0][1]).max())   # (sums of 10^4 terms in another order)
+    assert np.abs(out[0][1]).max() > 0.0
+    if not dlm:
+        sums, gref, Eo, Io = co.loss_grad(cfg, sa, X, batch, w=w, gmask=gm)
+        assert util.rel_err(out[0][2], Eo) < 1e-8 and util.rel_err(out[0][3], Io) < 1e-7
+        np.testing.assert_allclose(out[0][0], sums.sum(axis=0), rtol=1e-9)
+        for sl in np.nonzero(gm)[0]:
+            assert np.max(np.abs(out[0][1][:, sl] - gref[:, sl])) <= 1e-6 * np.max(np.abs(gref)), sl
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_one_sweep_kernel_random_geometry(torch_mod, seed):
     """k_spectrum_fused on randomly drawn geometry: 3 to 24 scattering angles (the base-point exchange between lanes is taken

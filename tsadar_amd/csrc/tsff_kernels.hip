@@ -77,6 +77,7 @@ struct KCall {
 #include "k_spectrum.inc"
 constexpr int kFusedMaxIon = 2;  // k_spectrum_fused is instantiated for n_ion <= 2 (4 x (7 + 3 n_ion) register accumulators per thread)
 #include "k_spectrum_fused.inc"
+#include "k_spectrum_rows.inc"
 #include "k_form_factor.inc"
 #include "k_form_factor_2d.inc"
 #include "k_ats.inc"
