@@ -13,6 +13,7 @@
 namespace tsff {
 
 // static, per-handle device configuration (passed by value)
+constexpr int kTapPad = 16;   // zero padding of the taps for points_per_pixel > 1 (>= the largest ppp of k_spectrum_rows' bin-wise adjoint)
 struct KStatic {
   int npts, ppp, n_angles, G, nvx, NP;
   int shared_fe;  // 1: every lineout uses table slot 0
@@ -35,7 +36,7 @@ struct KStatic {
   int ntaps[2];              // length of the bin-averaged IRF taps hb
   int toff[2];               // ybin[p] = sum_s hb[s] x[p * ppp + toff + s]
   // phase-layout convolution (points_per_pixel = 1, 256 threads per feature; see "IRF convolution" in k_spectrum):
-  const double* ptaps[2];    // hb zero-padded by 3 + rounding on both sides: ptaps[3 + s] = hb[s]
+  const double* ptaps[2];    // points_per_pixel 1: hb zero-padded by 3 + rounding on both sides, ptaps[3 + s] = hb[s]; else by kTapPad, ptaps[kTapPad + s] = hb[s]
   int cf_i0[2], cf_na[2], cf_a0[2];  // forward: first padded-tap index, tap groups of 4, first slot offset (u0 / 4)
   int ca_i0[2], ca_na[2], ca_a0[2];  // adjoint: first (descending) padded-tap index, groups, slot offset
   int hs;                    // halo of a phase array in slots of 4 samples
