@@ -1322,10 +1322,12 @@ def test_rows_kernel_points_per_pixel(torch_mod, ppp, n_ion, active):
     X = util.normed_to_matrix(normed, n_ion)
     gm = eng.slots.active.astype(np.uint8)
     out = {}
-    for plan in (0, 2):
+    for plan in (0, 8, 2):   # rows kernel with / without the base-point exchange between lanes, two-sweep kernel
         eng.set_launch_plan(plan)
         out[plan] = [a.cpu().numpy() for a in eng.loss_grad(X, batch, w, gm, want_spectra=True)]
     eng.set_launch_plan(0)
+    for k in range(4):
+        np.testing.assert_array_equal(out[0][k], out[8][k])
     for k in (2, 3):
         np.testing.assert_array_equal(out[0][k], out[2][k])
     # (the loss sums are folded over 256 threads x 4 bins here, over 512 x 2 by the two-sweep kernel's one-feature workgroups)
