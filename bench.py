@@ -351,7 +351,8 @@ def main():
     achieved = B * abytes / kavg_s / 1e9
     res = {
         "metric": ("spectra/sec (fwd+grad), 1024-lambda EPW+IAW form factor, batch 4096" if not args.forward_only
-                   else "spectra/sec (forward only), 1024-lambda EPW+IAW form factor") + (" [DLM variant: per-lineout f_e]" if args.dlm else "") + (" [free-form f_e variant: + gradient w.r.t. f_e]" if args.free_form else ""),
+                   else "spectra/sec (forward only), 1024-lambda EPW+IAW form factor") + (" [DLM variant: per-lineout f_e]" if args.dlm else "") + (" [free-form f_e variant: + gradient w.r.t. f_e]" if args.free_form else "")
+                  + (" [variant: %d points per pixel = %d wavelength samples per feature, batch %d per GPU]" % (args.ppp, 1024 * args.ppp, B) if args.ppp != 1 else ""),
         "value": value,
         "unit": "spectra/s",
         "n_gpus": world,
@@ -390,7 +391,9 @@ def main():
             "algorithmic_bytes_per_launch": B * abytes,
             "kernel": ("k_spectrum<1,0,0,256,false>" if args.forward_only else
                        ("k_spectrum<1,1,2,256,false> (two-sweep kernel with table adjoints)" if args.free_form else
-                        "k_spectrum_fused<1,%d,false> (one launch of 2B 256-thread workgroups, one sweep over the points)" % (1 if args.dlm else 0))
+                        ("k_spectrum_fused<1,%d,false> (one launch of 2B 256-thread workgroups, one sweep over the points)" % (1 if args.dlm else 0)
+                         if args.ppp == 1 else
+                         "k_spectrum_rows<1,%d> (points_per_pixel %d: one sweep in rounds of 1024 samples, Jacobian rows in a global scratch array)" % (1 if args.dlm else 0, args.ppp)))
                        if not (args.plan & 2) else "k_spectrum<1,1,GM,256,false> (two-sweep kernel)"),
             "kernel_avg_ms": kavg_s * 1e3,
             "kernel_median_ms": kmed_ms,
