@@ -153,8 +153,10 @@ int tsff_set_stream(tsff_handle *h, void *hip_stream);
  * (LossFunction._loss_for_hess_fn_, loss_function.py:173-188, the loss whose Hessian gives the fit uncertainties).
  * TSFF_OPT_LAUNCH_PLAN: bit mask, 0 (default) automatic -- with two loaded features one launch of 2B 256-thread workgroups, one
  * per (lineout, feature), when two of them fit a CU; tsff_loss_grad runs the one-sweep kernel (forward value and Jacobian rows
- * of every wavelength sample in one pass over the points) where it applies: one gradient point, one point per pixel, n_ion <= 2,
- * no gradient w.r.t. the tabulated f_e.  Bit 0: never interleave (both features in one 512-thread workgroup); bit 1: always the
+ * of every wavelength sample in one pass over the points) where it applies: one gradient point, n_ion <= 2, no gradient w.r.t.
+ * the tabulated f_e; with one point per pixel the rows stay in registers, with more (the reference's default decks: 5) they go
+ * through a scratch array in device memory that the handle allocates on first use: B x loaded features x (8 + 3 n_ion) x npts
+ * doubles, 1 GB at B = 1024 and 5 points per pixel (above 16 GB the two-sweep kernel is used instead).  Bit 0: never interleave (both features in one 512-thread workgroup); bit 1: always the
  * two-sweep kernel; bit 2: never three forward-only workgroups per CU (tsff_forward runs three 256-thread workgroups per CU when
  * the batch is large enough to need them); bit 3: the one-sweep kernel evaluates every base point itself instead of taking its pair's
  * right neighbour from the next lane.  The spectra are identical either way; the gradient differs by rounding. */
