@@ -1,6 +1,6 @@
 """End-to-end cost of the fit step and of a whole fit at B = 4096: LossFunction.vg_loss ms per call with a
 kernel / PCIe+host split, and one scipy L-BFGS-B fit exactly as the reference drives it (inverse/loops.py:43-51, maxiter =
-num_epochs = 120).  Writes profiles/<tag>_fit_timing.json (and gpurun_out/).   usage: python scripts/fit_timing.py <tag> [B]"""
+num_epochs = 120).  Writes profiles/<tag>_fit_timing.json (and gpurun_out/).   usage: python scripts/fit_timing.py <tag> [B] [points_per_pixel]"""
 import cProfile, io, json, os, pstats, sys, time
 import numpy as np, torch, scipy.optimize as spopt
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,8 @@ from tsadar_amd.calibration import sa_lookup
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "fit"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-cfg = S.baseline_deck(batch_size=B)
+PPP = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+cfg = S.baseline_deck(points_per_pixel=PPP, batch_size=B)
 cfg["optimizer"]["method"] = "l-bfgs-b"
 sa = sa_lookup("P9"); sa = dict(sa=sa["sa"], weights=sa["weights"] * np.ones([B, 10]))
 rng = np.random.default_rng(S.SEED)
@@ -35,7 +36,7 @@ t = time.perf_counter()
 for _ in range(n): v, g = lf.vg_loss(x0, static, hb)
 dt_call = (time.perf_counter() - t) / n * 1e3
 kt = eng.kernel_times_ms()
-res = {"B": B, "free_params_per_lineout": len(diff.values), "unknowns": int(x0.size),
+res = {"B": B, "points_per_pixel": PPP, "free_params_per_lineout": len(diff.values), "unknowns": int(x0.size),
        "vg_loss_ms_per_call": dt_call, "kernel_ms_avg": float(np.mean(kt)), "kernel_ms_median": float(np.median(kt)),
        "host_pcie_ms_per_call": dt_call - float(np.mean(kt)),
        "host_pcie_over_kernel": (dt_call - float(np.mean(kt))) / float(np.mean(kt))}
