@@ -1342,6 +1342,35 @@ def test_rows_kernel_points_per_pixel(torch_mod, ppp, n_ion, active):
             assert np.max(np.abs(out[0][1][:, sl] - gref[:, sl])) <= 1e-6 * np.max(np.abs(gref)), sl
 
 
+@pytest.mark.parametrize("ele,ion", [(True, False), (False, True)])
+def test_rows_kernel_single_feature(torch_mod, ele, ion):
+    """k_spectrum_rows with ONE loaded feature (grid B, gradient written directly instead of through the per-feature parts),
+    3 points per pixel: loss and gradient against the two-sweep kernel and the oracle's loss."""
+    cfg = decks.deck_fit(points_per_pixel=3)
+    ext = cfg["other"]["extraoptions"]
+    ext["load_ele_spec"], ext["load_ion_spec"] = ele, ion
+    ext["fit_EPWb"] = ext["fit_EPWr"] = ele
+    ext["fit_IAW"] = ion
+    B = 3
+    sa, batch, normed, i_norm, e_norm = _loss_setup(decks.deck_fit(points_per_pixel=3), B, seed=61)
+    eng = _engine(cfg, sa)
+    X = util.normed_to_matrix(normed, 1)
+    w = eng.loss_weights(B, i_norm, e_norm)
+    gm = eng.slots.active.astype(np.uint8)
+    out = {}
+    for plan in (0, 2):
+        eng.set_launch_plan(plan)
+        out[plan] = [a.cpu().numpy() for a in eng.loss_grad(X, batch, w, gm, want_spectra=True)]
+    eng.set_launch_plan(0)
+    for k in (2, 3):
+        np.testing.assert_array_equal(out[0][k], out[2][k])
+    np.testing.assert_allclose(out[0][0], out[2][0], rtol=1e-14)
+    np.testing.assert_allclose(out[0][1], out[2][1], rtol=1e-10, atol=1e-12 * np.abs(out[0][1]).max())
+    assert np.abs(out[0][1]).max() > 0.0
+    lo, _, _ = orc.loss(cfg, sa, normed, batch, i_norm, e_norm)
+    assert abs(float(np.dot(out[0][0], w)) - lo) < 1e-9 * abs(lo)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_one_sweep_kernel_random_geometry(torch_mod, seed):
     """k_spectrum_fused / k_spectrum_rows (1, 2, 3, 5 points per pixel) on randomly drawn geometry: 3 to 24 scattering angles (the base-point exchange between lanes is taken
