@@ -1302,12 +1302,14 @@ def test_launch_plans_agree(torch_mod):
 
 
 @pytest.mark.parametrize("ppp,n_ion,active", [(5, 1, ("Te", "ne", "Ti", "Va", "lam", "amp1")), (2, 2, ("Te", "ne", "Ti", "Z", "Va", "ud", "lam", "amp1", "amp2", "amp3")),
-                                              (3, 1, ("Te", "ne", "m", "amp1", "amp2", "lam"))])
+                                              (3, 1, ("Te", "ne", "m", "amp1", "amp2", "lam")), (4, 1, ("Te", "ne", "Ti", "lam", "amp3")),
+                                              (6, 1, ("Te", "ne", "Ti", "Va", "lam", "amp1"))])
 def test_rows_kernel_points_per_pixel(torch_mod, ppp, n_ion, active):
     """k_spectrum_rows (points_per_pixel > 1: the one-sweep kernel with its Jacobian rows in a global scratch array) against
     the two-sweep kernel on the same deck -- spectra and loss sums the same bits, gradient to 1e-11 -- and against the C++
     oracle; 5 points per pixel is the reference's default deck shape (tests/configs/1d-defaults.yaml:100); the third case
-    fits the DLM order per lineout (tangent tables, GM = 1)."""
+    fits the DLM order per lineout (tangent tables, GM = 1); 6 points per pixel takes the kernel's generic convolution forms
+    (the fast ones are instantiated for 2 to 5) if two workgroups still fit a CU, else the two-sweep kernel on both sides."""
     from oracle import c_oracle as co
 
     dlm = "m" in active
