@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--arts", action="store_true",
                     help="the 2-D angular form factor at the reference's ARTS size (128 x 128 f_e in LDS, 241 angles x 1024 lambda); "
                          "like --config4 a parity-unpinned path, not the headline metric")
+    ap.add_argument("--irf-cutoff", type=float, default=12.0,
+                    help="IRF taps kept within this many standard deviations (engine default 12: the reference's full-length convolution to the "
+                         "last bit of a spectrum's 1e-22 tails; 8: differences below 1e-14 of the spectrum's maximum; not the headline setting)")
     ap.add_argument("--plan", type=int, default=0, help="launch plan bit mask (experiments): 0 automatic, 1 never interleave the features, 2 two-sweep kernel instead of the one-sweep one")
     args = ap.parse_args()
     if args.config4 or args.arts:
@@ -250,7 +253,7 @@ def main():
     sa = dict(sa=sa["sa"], weights=sa["weights"] * np.ones([B, 10]))  # lineouts.py:103
     from tsadar_amd import _lib as L
 
-    eng = Engine(cfg, sa, activate=True, fe_mode=L.FE_PER_LINEOUT if args.free_form else None)
+    eng = Engine(cfg, sa, activate=True, fe_mode=L.FE_PER_LINEOUT if args.free_form else None, irf_cutoff_sigmas=args.irf_cutoff)
 
     if args.plan:
         eng.set_launch_plan(args.plan)
