@@ -1389,10 +1389,11 @@ def test_one_sweep_kernel_random_geometry(torch_mod, seed):
     other = cfg["other"]
     lo = float(rng.choice([400.0, 450.0, 500.0, 528.5, 540.0]))
     hi = float(rng.choice([520.0, 526.0, 560.0, 700.0])) if lo < 520.0 else float(rng.choice([600.0, 700.0]))
-    other["lamrangE"] = [lo, hi]
     c = float(rng.uniform(526.0, 527.0))
     hw = float(rng.choice([0.4, 0.75, 2.5]))
-    other["lamrangI"] = [c - hw, c + hw]
+    r0 = cfg["data"]["fit_rng"]   # (decks.finish derives lamrangE / lamrangI from these)
+    r0["forward_epw_start"], r0["forward_epw_end"] = lo, hi
+    r0["forward_iaw_start"], r0["forward_iaw_end"] = c - hw, c + hw
     # (IRF widths in units of the sample spacing like the shipped decks', up to twice as wide; with several points per pixel the
     #  ion IRF stays below 1.4 x the shipped width: beyond ~1000 taps the spectrum + halo no longer fit the LDS and tsff_create says so)
     other["PhysParams"]["widIRF"] = {"spect_stddev_ele": float(rng.uniform(0.5, 2.0)) * (hi - lo) / 300.0,
