@@ -1373,6 +1373,30 @@ def test_rows_kernel_single_feature(torch_mod, ele, ion):
     assert abs(float(np.dot(out[0][0], w)) - lo) < 1e-9 * abs(lo)
 
 
+def test_wide_irf_cuts_taps_instead_of_failing(torch_mod):
+    """5 points per pixel with an ion IRF five times as wide as the shipped decks': at 12 sigma the spectrum + halo + taps outgrow the LDS
+    of a CU.  The engine drops the outermost taps step by step (never below 7 sigma) with a warning instead of refusing the deck;
+    the result equals the oracle's full-length convolution to the weight of the dropped taps."""
+    import warnings
+
+    cfg = decks.deck_fit(points_per_pixel=5)
+    cfg["other"]["PhysParams"]["widIRF"]["spect_stddev_ion"] = 0.075
+    B = 2
+    sa, batch, normed, i_norm, e_norm = _loss_setup(cfg, B, seed=71)
+    with warnings.catch_warnings(record=True) as wrn:
+        warnings.simplefilter("always")
+        eng = _engine(cfg, sa)
+    assert 7.0 <= eng.irf_cutoff_sigmas < 12.0 and any("IRF taps cut" in str(w.message) for w in wrn)
+    X = util.normed_to_matrix(normed, 1)
+    E, I = eng.forward(X, batch["e_amps"], batch["i_amps"], batch["noise_e"], batch["noise_i"])
+    Eo, Io, _, _ = orc.ts_diag(cfg, sa, normed, batch)
+    assert util.rel_err(E.cpu().numpy(), Eo) < 1e-8 and util.rel_err(I.cpu().numpy(), Io) < 1e-8
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    terms, grad, _, _ = eng.loss_grad(X, batch, w, eng.slots.active.astype(np.uint8))
+    lo, _, _ = orc.loss(cfg, sa, normed, batch, i_norm, e_norm)
+    assert abs(float(np.dot(terms.cpu().numpy(), w)) - lo) < 1e-8 * abs(lo) and bool(torch_mod.isfinite(grad).all())
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_one_sweep_kernel_random_geometry(torch_mod, seed):
     """k_spectrum_fused / k_spectrum_rows (1, 2, 3, 5 points per pixel) on randomly drawn geometry: 3 to 24 scattering angles (the base-point exchange between lanes is taken

@@ -175,16 +175,19 @@ class Engine:
         c.norm = int(phys["norm"])
         lamE = wavelength_axis_nm(other["lamrangE"], self.npts)
         lamI = wavelength_axis_nm(other["lamrangI"], self.npts)
-        if self.load_ele:
-            t, d0 = gaussian_taps(lamE, float(phys["widIRF"]["spect_stddev_ele"]), irf_cutoff_sigmas)
-            t, off = binned_taps(t, d0, self.npts // L.NBINS)
-            a, c.taps_ele = _as_c(t, np.float64); keep.append(a)
-            c.n_taps_ele, c.tap_off_ele = t.size, off
-        if self.load_ion and phys["widIRF"]["spect_stddev_ion"]:
-            t, d0 = gaussian_taps(lamI, float(phys["widIRF"]["spect_stddev_ion"]), irf_cutoff_sigmas)
-            t, off = binned_taps(t, d0, self.npts // L.NBINS)
-            a, c.taps_ion = _as_c(t, np.float64); keep.append(a)
-            c.n_taps_ion, c.tap_off_ion = t.size, off
+        def set_taps(cutoff):
+            if self.load_ele:
+                t, d0 = gaussian_taps(lamE, float(phys["widIRF"]["spect_stddev_ele"]), cutoff)
+                t, off = binned_taps(t, d0, self.npts // L.NBINS)
+                a, c.taps_ele = _as_c(t, np.float64); keep.append(a)
+                c.n_taps_ele, c.tap_off_ele = t.size, off
+            if self.load_ion and phys["widIRF"]["spect_stddev_ion"]:
+                t, d0 = gaussian_taps(lamI, float(phys["widIRF"]["spect_stddev_ion"]), cutoff)
+                t, off = binned_taps(t, d0, self.npts // L.NBINS)
+                a, c.taps_ion = _as_c(t, np.float64); keep.append(a)
+                c.n_taps_ion, c.tap_off_ion = t.size, off
+
+        set_taps(irf_cutoff_sigmas)
         filt = other.get("iawfilter", [0, 0, 0, 0])
         if self.load_ele and filt[0]:
             fb, fr = filt[3] - filt[2] / 2, filt[3] + filt[2] / 2
@@ -228,8 +231,24 @@ class Engine:
         self._staging = {}
         self._cfg_struct = c
         h = C.c_void_p()
-        rc = self.lib.tsff_create(C.byref(c), C.byref(h))
+        cutoff = irf_cutoff_sigmas
+        while True:
+            rc = self.lib.tsff_create(C.byref(c), C.byref(h))
+            msg = self.lib.tsff_last_error(None) if rc else b""
+            # Wide instrument functions at several points per pixel: spectrum + halo + taps outgrow the LDS of a CU.  The taps
+            # beyond ~8 sigma only matter below 1e-14 of a spectrum's maximum (they reproduce the reference's full-length
+            # convolution in the 1e-22 tails): drop them step by step down to 7 sigma (2e-11) before giving up, and say so.
+            if rc == -2 and msg and b"LDS budget exceeded" in msg and cutoff and cutoff > 7.0:
+                cutoff = max(7.0, cutoff - 1.0)
+                set_taps(cutoff)
+                continue
+            break
         L.check(self.lib, None, rc)
+        if cutoff != irf_cutoff_sigmas:
+            import warnings
+            warnings.warn(f"tsadar_amd: IRF taps cut at {cutoff} sigma instead of {irf_cutoff_sigmas} to fit the LDS "
+                          f"(relative weight of the dropped taps below {np.exp(-0.5 * cutoff ** 2):.1e})")
+        self.irf_cutoff_sigmas = cutoff
         self.h = h
         self.device = torch.device("cuda", torch.cuda.current_device())
         # axes as the library computed them
