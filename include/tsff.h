@@ -159,7 +159,8 @@ int tsff_set_stream(tsff_handle *h, void *hip_stream);
  * doubles, 1 GB at B = 1024 and 5 points per pixel (above 16 GB the two-sweep kernel is used instead).  Bit 0: never interleave (both features in one 512-thread workgroup); bit 1: always the
  * two-sweep kernel; bit 2: never three forward-only workgroups per CU (tsff_forward runs three 256-thread workgroups per CU when
  * the batch is large enough to need them); bit 3: the one-sweep kernel evaluates every base point itself instead of taking its pair's
- * right neighbour from the next lane.  The spectra are identical either way; the gradient differs by rounding. */
+ * right neighbour from the next lane; bit 5 (32): the per-lineout W tables by the 128 x 128-tiled GEMM instead of the 128 x 144 one (bit 4 is
+ * unused and refused).  The spectra are identical either way; the gradient differs by rounding. */
 enum { TSFF_OPT_DENOM_MODE = 1, TSFF_OPT_LAUNCH_PLAN = 2 };
 int tsff_set_option(tsff_handle *h, int32_t key, int32_t value);
 /* make sure the workspace holds B lineouts (calls grow it lazily; not inside graph capture) */
