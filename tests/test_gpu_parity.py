@@ -1324,12 +1324,19 @@ def test_rows_kernel_points_per_pixel(torch_mod, ppp, n_ion, active):
     X = util.normed_to_matrix(normed, n_ion)
     gm = eng.slots.active.astype(np.uint8)
     out = {}
-    for plan in (0, 8, 2):   # rows kernel with / without the base-point exchange between lanes, two-sweep kernel
+    # rows kernel (small batch: one workgroup per round, the last to finish runs the chain) / without the base-point exchange
+    # between lanes / one workgroup for all rounds (the large-batch form) / two-sweep kernel
+    for plan in (0, 8, 1, 2):
         eng.set_launch_plan(plan)
         out[plan] = [a.cpu().numpy() for a in eng.loss_grad(X, batch, w, gm, want_spectra=True)]
     eng.set_launch_plan(0)
     for k in range(4):
         np.testing.assert_array_equal(out[0][k], out[8][k])
+        np.testing.assert_array_equal(out[0][k], out[1][k])
+    for rep in range(3):   # (the split form hands rows between workgroups: the same bits every time)
+        again = [a.cpu().numpy() for a in eng.loss_grad(X, batch, w, gm, want_spectra=True)]
+        for k in range(4):
+            np.testing.assert_array_equal(out[0][k], again[k])
     for k in (2, 3):
         np.testing.assert_array_equal(out[0][k], out[2][k])
     # (the loss sums are folded over 256 threads x 4 bins here, over 512 x 2 by the two-sweep kernel's one-feature workgroups)
