@@ -34,6 +34,40 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12      # B/s, spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 FP64_PEAK = 78.6e12    # flop/s, AMD public spec for FP64 vector (not in the local guide)
 FLOP_PER_SPECTRUM = 13.0e6  # forward + adjoint, shared W table
+FLOP_PER_SPECTRUM_FWD = 4.3e6  # forward only (4 MFLOP of points + 0.3 MFLOP of instrument function)
+N_SIMD = 1024               # 256 CUs x 4 SIMDs: a VALU instruction occupies its SIMD's issue port for 4 cycles
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the N ranks as FRESH processes
+    (``python -m torch.distributed.run`` on 127.0.0.1, one rank per GPU) before this process has imported torch or touched
+    the GPU, pass their stdout's one JSON line through and exit with their code.  (The driver's own
+    ``python -m torch.distributed.run ... bench.py --gpus N`` sets WORLD_SIZE and never comes through here.)"""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in p.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)   # (anything a rank wrote to stdout besides the line)
+    if p.returncode != 0:
+        print(f"bench.py: the {args.gpus}-rank launch failed with exit code {p.returncode}", file=sys.stderr)
+        return p.returncode
+    if len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    print(lines[0])
+    return 0
 
 
 def algorithmic_bytes(NP: int, with_noise: bool) -> int:
@@ -149,6 +183,7 @@ def config4_main(args):
     samples = float(npts) * na * nv * nv            # bicubic samples per image: every point rotates the whole table
     stencil_bytes = samples * 16 * 8                # 4 x 4 doubles per sample, read through L1/L2 (the table is 532 KB)
     flop = samples * 60.0                           # two Catmull-Rom weight sets (~24) + 16-term contraction (~36)
+    req_bytes = stencil_bytes if arts else stencil_bytes / 2   # what the kernel loads per sample: all 16 entries (LDS) / the entering row + column
     res = {
         "metric": "2-D angular form-factor images/s (forward), %dx%d f_e, %d angles x 1024 lambda" % (nv, nv, na),
         "value": steps / dt, "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * dt / steps,
@@ -158,20 +193,21 @@ def config4_main(args):
                                ("configs[3]: arts-2d angular, non-Maxwellian f_e on a 256x256 v-grid, 512 scattering angles x 1024 lambda, "
                                 "one plasma condition (parity unpinned against the reference; pinned to the oracle)"),
                    "nv": nv, "n_angles": na, "n_lambda": npts, "points": npts * na, "bicubic_samples": samples},
-        "roofline": {"bound": "lds" if arts else "l1", "achieved": stencil_bytes / kavg_s / 1e12, "peak": lds_peak if arts else l1_peak, "unit": "TB/s",
-                     "frac": stencil_bytes / kavg_s / 1e12 / (lds_peak if arts else l1_peak), "traffic": None,
+        # configs[3] (table through L1/L2): the sampler keeps the 4 x 4 stencil in a rolling register window and REQUESTS only the entering
+        # row and column -- 64 B per sample; the roofline counts the bytes the kernel loads, not the 128 B of stencil a sample consumes
+        "roofline": {"bound": "lds" if arts else "l1", "achieved": req_bytes / kavg_s / 1e12, "peak": lds_peak if arts else l1_peak, "unit": "TB/s",
+                     "frac": req_bytes / kavg_s / 1e12 / (lds_peak if arts else l1_peak), "traffic": None,
                      "kernel": "k_form_factor_2d<1,true,4,false> (table in LDS, one ds_read_b64 per stencil entry)" if arts else
                                "k_form_factor_2d<1,false,1,false> (table read through L1/L2 from the padded copy of k_pad2d and its transpose; rolling 4x4 window)",
                      "kernel_avg_ms": kavg_s * 1e3, "kernel_median_ms": float(np.median(kt)),
-                     "algorithmic_bytes_per_launch": stencil_bytes,
-                     "note": ("achieved = 128 B of stencil per bicubic sample x samples / kernel time; peak = 256 B per clock and CU of ds_read_b64 x 256 CUs x "
-                              "2.4 GHz (conflict-free; the sampler's rotated lines measure 2.0 passes per read); the kernel issues 75 VALU instructions per "
-                              "sample and is VALU-issue bound first (fp64_valu)") if arts else
-                             ("achieved = 128 B of stencil per bicubic sample x samples / kernel time; peak = vector-L1 read rate measured on "
-                              "this device by tsff_l1_read_peak (16-byte loads from a 16 KB window); HBM traffic is the 532 KB table + 4 MB of P. "
-                              "Since round 2 the sampler keeps the stencil in a rolling register window and REQUESTS 64 B per sample (the entering "
-                              "row and column): requested = achieved / 2; it is VALU-issue bound (121 instructions per sample, SQ busy 0.87)"),
-                     "requested_tbps": None if arts else stencil_bytes / 2 / kavg_s / 1e12,
+                     "algorithmic_bytes_per_launch": req_bytes,
+                     "note": ("achieved = 128 B of stencil read from LDS per bicubic sample x samples / kernel time; peak = 256 B per clock and CU of "
+                              "ds_read_b64 x 256 CUs x 2.4 GHz (conflict-free; the sampler's rotated lines measure 2.0 passes per read); the kernel is "
+                              "VALU-issue bound first (fp64_valu)") if arts else
+                             ("achieved = the 64 B per bicubic sample the rolling window REQUESTS (entering row + column of the 4 x 4 stencil) x samples / "
+                              "kernel time; peak = vector-L1 read rate measured on this device by tsff_l1_read_peak (16-byte loads from a 16 KB window); "
+                              "HBM traffic is the 532 KB table + 4 MB of P.  The binding resource is VALU issue, see fp64_valu / "
+                              "profiles/*_2d_sq_counters.json"),
                      "fp64_valu": {"achieved_tflops": flop / kavg_s / 1e12, "peak": FP64_PEAK / 1e12, "frac": flop / kavg_s / FP64_PEAK,
                                    "flop_per_sample": 60.0}},
     }
@@ -207,6 +243,8 @@ def main():
                          "last bit of a spectrum's 1e-22 tails; 8: differences below 1e-14 of the spectrum's maximum; not the headline setting)")
     ap.add_argument("--plan", type=int, default=0, help="launch plan bit mask (experiments): 0 automatic, 1 never interleave the features, 2 two-sweep kernel instead of the one-sweep one")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     if args.config4 or args.arts:
         return config4_main(args)
     variant = args.dlm or args.free_form
@@ -281,6 +319,11 @@ def main():
     # the buffer of the step's one collective and one D2H copy: [3 | P x B_global], written by the gradient kernels
     packed = torch.zeros(3 + P * B * world, dtype=torch.float64, device=dev)
 
+    # (N > 1) one event pair per step around the all-reduce, on the stream the kernels run on: the first fires when this rank's
+    # kernels are done, the second when the reduced buffer is back -- collective + waiting for the slowest rank
+    ar_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if world > 1 else []
+    ar_i = [-args.warmup]
+
     def step():
         if args.forward_only:
             return eng.forward(X, batch["e_amps"], batch["i_amps"])
@@ -290,7 +333,14 @@ def main():
             return D.allreduce_loss_grad(terms, g, world, rank)
         eng.loss_grad_packed(X, batch, w, gmask, act_slots, B * world, rank * B, out=packed)
         if world > 1:
-            dist.all_reduce(packed)
+            i = ar_i[0]
+            ar_i[0] += 1
+            if 0 <= i < len(ar_ev):
+                ar_ev[i][0].record()
+                dist.all_reduce(packed)
+                ar_ev[i][1].record()
+            else:
+                dist.all_reduce(packed)
         return packed
 
     def fence():
@@ -308,10 +358,21 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ktimes = eng.kernel_times_ms()
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        ar_ms = [a.elapsed_time(b) for a, b in ar_ev[:max(0, min(ar_i[0], len(ar_ev)))]]
+        mine = torch.tensor([float(np.mean(ktimes)) if ktimes.size else float("nan"), float(np.mean(ar_ms)) if ar_ms else float("nan"),
+                             float(np.median(ar_ms)) if ar_ms else float("nan")], dtype=torch.float64, device=dev)
+        allr = torch.empty(3 * world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, 3).cpu().numpy()
+        per_rank = {"kernel_avg_ms": [float(v) for v in allr[:, 0]], "allreduce_avg_ms": [float(v) for v in allr[:, 1]],
+                    "allreduce_median_ms": [float(v) for v in allr[:, 2]],
+                    "note": ("per rank: HIP-event average of the gradient kernel; event pair around dist.all_reduce on the kernels' stream "
+                             "(collective + waiting for the slowest rank); payload %d B" % (8 * packed.numel()))}
     ms_per_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
 
@@ -352,6 +413,22 @@ def main():
             traffic = tj["hbm_bytes_per_launch"]
     abytes = algorithmic_bytes(eng.NP, with_noise=False) if not args.forward_only else (eng.NP * 8 + 16 + 2 * 1024 * 8)
     achieved = B * abytes / kavg_s / 1e9
+    flop_spec = FLOP_PER_SPECTRUM_FWD if args.forward_only else FLOP_PER_SPECTRUM
+    # issue-slot utilisation of the VALU from the committed SQ counters of this very kernel and workload (rocprofv3 --pmc cannot run
+    # inside bench.py): SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles) -- NOT the algorithmic-flop fraction next to it
+    issue = None
+    kname = "k_spectrum<1, 0, 0" if args.forward_only else "k_spectrum_fused<1, 0"
+    if not variant and args.ppp == 1 and args.nvx == 128 and not (args.plan & 2):
+        for cf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")), reverse=True):
+            cj = json.load(open(cf))
+            c = {k: v["avg"] for k, v in cj.get("counters", {}).items()}
+            if cj.get("kernel_substring", "").startswith(kname) and cj.get("B", 4096) == B and "SQ_INSTS_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
+                cyc = c["GRBM_GUI_ACTIVE"] / 8.0   # (summed over the 8 XCDs)
+                issue = {"issue_slot_frac": c["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * cyc), "valu_instructions_per_launch": c["SQ_INSTS_VALU"],
+                         "kernel_cycles": cyc, "counters_file": "profiles/" + os.path.basename(cf)}
+                if "SQ_ACTIVE_INST_VALU" in c:
+                    issue["valu_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cyc)
+                break
     res = {
         "metric": ("spectra/sec (fwd+grad), 1024-lambda EPW+IAW form factor, batch 4096" if not args.forward_only
                    else "spectra/sec (forward only), 1024-lambda EPW+IAW form factor") + (" [DLM variant: per-lineout f_e]" if args.dlm else "") + (" [free-form f_e variant: + gradient w.r.t. f_e]" if args.free_form else "")
@@ -392,7 +469,7 @@ def main():
             "traffic": traffic,
             "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % (os.path.basename(tfile) if tfile else "-"),
             "algorithmic_bytes_per_launch": B * abytes,
-            "kernel": ("k_spectrum<1,0,0,256,false>" if args.forward_only else
+            "kernel": ("k_spectrum<1,0,0,256,*> (forward only)" if args.forward_only else
                        ("k_spectrum<1,1,2,256,false> (two-sweep kernel with table adjoints)" if args.free_form else
                         ("k_spectrum_fused<1,%d,false> (one launch of 2B 256-thread workgroups, one sweep over the points)" % (1 if args.dlm else 0)
                          if args.ppp == 1 else
@@ -405,15 +482,21 @@ def main():
         },
         "roofline_fp64": {
             "bound": "fp64-valu",
-            "achieved": B * FLOP_PER_SPECTRUM / kavg_s / 1e12,
+            "achieved": B * flop_spec / kavg_s / 1e12,
             "peak": FP64_PEAK / 1e12,
             "unit": "TFLOP/s",
-            "frac": B * FLOP_PER_SPECTRUM / kavg_s / FP64_PEAK,
-            "algorithmic_flop_per_spectrum": FLOP_PER_SPECTRUM,
+            "frac": B * flop_spec / kavg_s / FP64_PEAK,
+            "algorithmic_flop_per_spectrum": flop_spec,
             "peak_measured_fma": fp64_measured,
-            "frac_of_measured": B * FLOP_PER_SPECTRUM / kavg_s / 1e12 / fp64_measured,
+            "frac_of_measured": B * flop_spec / kavg_s / 1e12 / fp64_measured,
+            "note": ("frac: SURVEY.md 8(d)'s algorithmic flop count (an estimate made before the kernels existed) / kernel time / 78.6 TF; "
+                     "issue_slot_frac: what the VALU actually issued, from the committed counters -- the two are different quantities"),
         },
     }
+    if issue is not None:
+        res["roofline_fp64"].update(issue)
+    if per_rank is not None:
+        res["per_rank"] = per_rank
     if pcie_value is not None:
         res["value_pcie_inclusive"] = pcie_value
         res["value_note"] = ("value: inputs resident in HBM, [3 | P x B] loss + gradient left in HBM; value_pcie_inclusive: + params "

@@ -44,6 +44,11 @@ extern "C" {
 #endif
 
 #define TSFF_ABI_VERSION 7
+/* error codes (every entry point returns 0 or one of these; text via tsff_last_error):
+ * -1 bad argument, -2 unsupported configuration / option, -3 not a differentiable leaf, -5 HIP runtime error,
+ * TSFF_ERR_LDS: the configuration needs more LDS than a CU has (wide instrument functions at several points per pixel:
+ * spectrum + halo + taps) -- the caller may retry with fewer IRF taps. */
+#define TSFF_ERR_LDS (-7)
 
 /* ---- parameter slots of one lineout: params[b][TSFF_NP(n_ion)] (normalised leaves of the
  * reference's ThomsonParams pytree, core/modules/ts_params.py:49-60,395-420,253-262) ---------- */

@@ -167,6 +167,145 @@ def test_three_ranks_uneven_batch_and_local_dummy_batch(tmp_path):
     np.testing.assert_allclose(r[0], want, rtol=1e-12, atol=1e-15)
 
 
+@pytest.mark.timeout(1200)
+def test_eight_ranks_uneven_batch_with_an_empty_shard(tmp_path):
+    """The world size of BASELINE configs[4] (8 ranks) on CPU: B = 20 over 8 gloo ranks -> shards of 3, 3, 3, 3, 3, 3, 2 and 0
+    lineouts (one rank only takes part in the collectives), LossFunction built from each rank's LOCAL shard.  Every rank ends
+    with the single-rank loss and gradient to 1e-12."""
+    B, world = 20, 8
+    port = _free_port()
+    mp.spawn(_rank_main, args=(world, port, B, str(tmp_path), True), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"flat_{k}.npy") for k in range(world)]
+    for k in range(1, world):
+        np.testing.assert_array_equal(r[0], r[k])
+    want = _reference(B)
+    assert r[0].shape == want.shape == (1 + 6 * B,)
+    np.testing.assert_allclose(r[0], want, rtol=1e-12, atol=1e-15)
+
+
+def _oracle_evaluate_free_form(self, ts_params, batch, want_spectra=False, B_global=None):
+    """Replacement for LossFunction._evaluate on the free-form f_e branch (tsff_loss_grad_fe on the GPU): oracle masked sums,
+    autodiff gradient of the weighted total w.r.t. this shard's normalised parameters and w.r.t. its f_e tables."""
+    import util
+    from oracle import tsadar_oracle_torch as ot
+    from tsadar_amd import distribution as Dist
+    from tsadar_amd.engine import Engine
+
+    X = ts_params.to_matrix()
+    B = X.shape[0]
+    eng = _OracleEngine(self.cfg)
+    eng.nvx = ts_params.fval.shape[1]
+    w = Engine.loss_weights(eng, B if B_global is None else B_global, self.i_norm, self.e_norm, self.cfg["data"]["ion_loss_scale"])
+    if B == 0:
+        self._gfe = torch.zeros((0, eng.nvx), dtype=torch.float64)
+        return eng, w, torch.zeros(3, dtype=torch.float64), torch.zeros((0, X.shape[1]), dtype=torch.float64), None, None
+    names = ["Te", "ne", "m", "Ti_1", "Z_1", "A_1", "fract_1", "lam", "amp1", "amp2", "amp3", "ne_gradient", "Te_gradient", "ud", "Va"]
+    normed = {k: torch.tensor(X[:, util.slot_of(k)], dtype=torch.float64, requires_grad=True) for k in names}
+    fe = torch.tensor(Dist.arbitrary_1v(ts_params.fval), dtype=torch.float64, requires_grad=True)
+    sa = dict(sa=util.P9["sa"], weights=util.P9["weights"] * np.ones([B, 10]))
+    S, N, E, I = ot.masked_sums(self.cfg_oracle, sa, normed, batch, fe_batch=fe)
+    total = (S * torch.as_tensor(w)).sum()
+    grads = torch.autograd.grad(total, [normed[k] for k in names] + [fe], allow_unused=True)
+    G = torch.zeros((B, X.shape[1]), dtype=torch.float64)
+    for k, g in zip(names, grads[:-1]):
+        if g is not None and ts_params.slots.active[util.slot_of(k)]:
+            G[:, util.slot_of(k)] = g
+    self._gfe = grads[-1]
+    return eng, w, S.detach(), G, E.detach(), I.detach()
+
+
+def _free_form_decks(nvx):
+    import decks
+
+    cfg = decks.deck_fit(nvx=nvx, active=("Te", "ne", "amp1", "lam"))
+    cfg["parameters"]["electron"]["fe"] = {"active": True, "type": "arbitrary", "dim": 1, "nvx": nvx, "params": {"init_m": 2.4}}
+    return cfg, decks.deck_fit(nvx=nvx, active=("Te", "ne", "amp1", "lam")), decks.deck_fit(nvx=nvx)
+
+
+def _free_form_inputs(B, nvx):
+    import util
+    from tsadar_amd import ThomsonParams
+
+    cfg, cfg_o, cfg_data = _free_form_decks(nvx)
+    batch = util.synthetic_batch(cfg_data, util.sa_fit(B), B, seed=81)
+    tp = ThomsonParams(cfg["parameters"], B, batch=True, activate=True)
+    rng = np.random.default_rng(4)
+    tp.fval = tp.fval * (1 + 0.02 * rng.normal(size=tp.fval.shape))
+    tp.X[:, 0] += rng.normal(size=B) * 0.1
+    return cfg, cfg_o, batch, tp
+
+
+def _rank_main_free_form(rank, world, port, B, nvx, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import util
+    from tsadar_amd import ThomsonParams, distributed as D, tree
+    from tsadar_amd.loss_function import LossFunction
+
+    D.init_from_env(backend="gloo")
+    cfg, cfg_o, batch, tp = _free_form_inputs(B, nvx)
+    lo, hi = D.shard_bounds(B, world, rank)
+    local = {k: np.asarray(v)[lo:hi] for k, v in batch.items()}
+    LossFunction._evaluate = _oracle_evaluate_free_form
+    lf = LossFunction(cfg, util.sa_fit(max(hi - lo, 1)), local, distributed=True)   # the LOCAL shard (empty on the last rank)
+    lf.cfg_oracle = cfg_o
+    spec = tree.get_filter_spec(cfg["parameters"], tp)
+    diff, _ = tree.partition(tp, spec)
+    x0, lf.unravel_weights = tree.ravel_pytree(diff)
+    tp_local = ThomsonParams(cfg["parameters"], hi - lo, batch=True, activate=True)
+    tp_local.X[:] = tp.X[lo:hi]
+    tp_local.fval = tp.fval[lo:hi].copy()
+    _, static_l = tree.partition(tp_local, tree.get_filter_spec(cfg["parameters"], tp_local))
+    value, flat = lf.vg_loss(x0, static_l, local)
+    np.save(os.path.join(out, f"ff_{rank}.npy"), np.concatenate([[value], flat]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_uneven_shards_on_the_free_form_branch(tmp_path):
+    """vg_loss with a free-form f_e (the branch that packs [P + nvx] rows with torch) over 4 ranks and B = 5: shards of 2, 2, 1
+    and 0 lineouts.  The 1/N of the loss must be the global count on every rank (it used to be B_local * world)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import tsadar_oracle as orc
+    from oracle import tsadar_oracle_torch as ot
+    from tsadar_amd import distribution as Dist
+    import util
+
+    B, world, nvx = 5, 4, 64
+    port = _free_port()
+    mp.spawn(_rank_main_free_form, args=(world, port, B, nvx, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"ff_{k}.npy") for k in range(world)]
+    for k in range(1, world):
+        np.testing.assert_array_equal(r[0], r[k])
+    cfg, cfg_o, batch, tp = _free_form_inputs(B, nvx)
+    names = ["Te", "ne", "lam", "amp1"]
+    normed = {k: tp.X[:, util.slot_of(k)].copy() for k in orc.init_normed_params(cfg_o["parameters"], B, True)}
+    i_norm, e_norm = orc.loss_norms(cfg, batch)
+    vo, ref, ref_fe, _, _ = ot.value_and_grad_fe(cfg_o, util.sa_fit(B), normed, batch, i_norm, e_norm, names, Dist.arbitrary_1v(tp.fval))
+    want = np.concatenate([[vo], ref["Te"], ref["ne"], Dist.arbitrary_1v_vjp(tp.fval, ref_fe).ravel(), ref["lam"], ref["amp1"]])
+    assert r[0].shape == want.shape
+    np.testing.assert_allclose(r[0], want, rtol=1e-10, atol=1e-13 * np.max(np.abs(want)))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` without a launcher around it starts two fresh rank processes itself (before the parent has
+    touched torch or the GPU).  On a box without a GPU both ranks must refuse to run -- "needs a HIP device", no CPU
+    fallback -- and the parent must pass the failure on as a non-zero exit code."""
+    import subprocess
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the launch itself is exercised by the driver's scaling run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-sample", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert p.stderr.count("bench.py needs a HIP device") >= 2, p.stderr[-3000:]
+    assert "but WORLD_SIZE=1" not in p.stderr
+    assert '"metric"' not in p.stdout
+
+
 def test_shard_bounds_and_single_rank_passthrough():
     from tsadar_amd import distributed as D
 

@@ -1067,13 +1067,13 @@ def test_random_decks_forward_loss_gradient(torch_mod, seed):
     E, I = eng.forward(X, batch["e_amps"], batch["i_amps"], batch["noise_e"], batch["noise_i"])
     # (1e-8 on the P9 fibre bundle; the random angle sets reach down to 25 degrees, where k lambda_De is small and the resonances
     #  are sharp enough for last-bit differences in k to show at 3e-8: seeds 150, 154, 159, 183 of a 200-seed soak)
-    tol = 1e-8 if seed < 5 else 1e-7
+    tol, ltol = (1e-8, 1e-9) if seed < 5 else (5e-8, 1e-8)
     assert util.rel_err(E.cpu().numpy(), Eo) < tol and util.rel_err(I.cpu().numpy(), Io) < tol, cfg["optimizer"]
     names = [k for k in normed if eng.slots.active[util.slot_of(k)]]
     w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
     terms, grad, _, _ = eng.loss_grad(X, batch, w, eng.slots.active.astype(np.uint8))
     val, ref, _, _ = ot.value_and_grad(cfg, sa, normed, batch, i_norm, e_norm, names)
-    assert abs(float(np.dot(terms.cpu().numpy(), w)) - val) < 10 * tol * abs(val), (cfg["optimizer"]["loss_method"], val)
+    assert abs(float(np.dot(terms.cpu().numpy(), w)) - val) < ltol * abs(val), (cfg["optimizer"]["loss_method"], val)
     Gd = util.matrix_to_named(grad.cpu().numpy(), names)
     scale = max(np.max(np.abs(v)) for v in ref.values())
     for k in names:

@@ -96,7 +96,7 @@ class Engine:
     """One libtsff handle for one (deck, scattering angles) pair on the current CUDA/HIP device."""
 
     def __init__(self, cfg: Dict, scattering_angles: Dict, activate: bool = True, fe_shared: Optional[np.ndarray] = None,
-                 fe_mode: Optional[int] = None, irf_cutoff_sigmas: float = 12.0):
+                 fe_mode: Optional[int] = None, irf_cutoff_sigmas: float = 12.0, irf_allow_cut: bool = True):
         import torch
 
         if not torch.cuda.is_available():
@@ -238,7 +238,8 @@ class Engine:
             # Wide instrument functions at several points per pixel: spectrum + halo + taps outgrow the LDS of a CU.  The taps
             # beyond ~8 sigma only matter below 1e-14 of a spectrum's maximum (they reproduce the reference's full-length
             # convolution in the 1e-22 tails): drop them step by step down to 7 sigma (2e-11) before giving up, and say so.
-            if rc == -2 and msg and b"LDS budget exceeded" in msg and cutoff and cutoff > 7.0:
+            # ``irf_allow_cut=False`` makes the overflow an error instead; the cut-off actually used is ``self.irf_cutoff_sigmas``.
+            if rc == L.ERR_LDS and irf_allow_cut and cutoff and cutoff > 7.0:
                 cutoff = max(7.0, cutoff - 1.0)
                 set_taps(cutoff)
                 continue

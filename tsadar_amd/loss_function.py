@@ -28,8 +28,10 @@ class LossFunction:
         self.distributed = distributed
         self.pg = process_group
         if cfg["optimizer"]["y_norm"]:  # loss_function.py:88-92
-            self.i_norm = float(np.amax(dummy_batch["i_data"]))
-            self.e_norm = float(np.amax(dummy_batch["e_data"]))
+            # (a rank whose shard is empty -- more ranks than lineouts -- contributes -inf to the max over the ranks)
+            amax = lambda a: float(np.amax(a)) if np.size(a) or not distributed else -np.inf
+            self.i_norm = amax(dummy_batch["i_data"])
+            self.e_norm = amax(dummy_batch["e_data"])
             if distributed:
                 self.i_norm, self.e_norm = D.allreduce_max([self.i_norm, self.e_norm], process_group)
         else:
@@ -88,16 +90,18 @@ class LossFunction:
         self._dev_batch = None
         self._ang_dev_src = None
 
-    def _evaluate(self, ts_params: ThomsonParams, batch, want_spectra=False):
-        """Local shard: -> (value, grad[B_local, NP] numpy, ThryE, ThryI).  In distributed mode the
-        value is the global loss (after the all-reduce) and grad the LOCAL block."""
-        import torch
-
+    def _evaluate(self, ts_params: ThomsonParams, batch, want_spectra=False, B_global=None):
+        """Local shard: -> (engine, weights, loss sums [3], grad[B_local, NP], ThryE, ThryI), all device tensors.  The 1/N of
+        the nanmean uses the TRUE global count ``B_global`` (shards may be uneven or empty, distributed.shard_bounds); without
+        it the shard is the whole batch."""
         eng = self.ts_diag.engine(ts_params.activate)
         X = ts_params.to_matrix()
         B = X.shape[0]
-        world, rank = self._world()
-        w = eng.loss_weights(B * world, self.i_norm, self.e_norm, self.cfg["data"]["ion_loss_scale"])
+        w = eng.loss_weights(B if B_global is None else B_global, self.i_norm, self.e_norm, self.cfg["data"]["ion_loss_scale"])
+        if B == 0:   # (more ranks than lineouts: this rank only takes part in the collective)
+            z = lambda *shape: eng.torch.zeros(shape, dtype=eng.torch.float64, device=eng.device)
+            self._gfe = z(0, eng.nvx) if ts_params.fval is not None else None
+            return eng, w, z(3), z(0, X.shape[1]), None, None
         db = self._device_batch(eng, batch, B)
         X = eng.upload(X)  # pinned staging, asynchronous H2D
         if ts_params.fval is not None:  # free-form f_e: explicit tables in, d loss / d fe out
@@ -314,7 +318,7 @@ class LossFunction:
         act = [s for _, s in ts_params.slots.active_leaves]
         if ts_params.fval is not None and ts_params.slots.fval_active:
             # free-form f_e: nvx more rows (d loss / d fe, chained on the host); packed by torch, one all-reduce all the same
-            eng, w, terms, grad, E, I = self._evaluate(ts_params, batch, want_spectra=not lbfgs)
+            eng, w, terms, grad, E, I = self._evaluate(ts_params, batch, want_spectra=not lbfgs, B_global=Bg)
             gact = torch.cat([grad[:, act].t(), self._gfe.t()]).contiguous()  # [P + nvx, B_local], ravel order
             out = D.allreduce_loss_grad(terms, gact, world, rank, self.pg, B_global=Bg, b_offset=lo)
             host = eng.download(out)
