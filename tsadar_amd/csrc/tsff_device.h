@@ -643,8 +643,14 @@ __device__ __forceinline__ double point_forward_sd(const Base& b, const Base& bn
 // w = ws - wL of one sign over the range (ws and k_s fall monotonically with the sample index).  Evaluated with
 // wavefront-uniform arguments; the result is made a scalar.
 template <int NI>
+__device__ __forceinline__ bool far_range_w(double w0, double w1, const LineS<NI>& L);
+template <int NI>
 __device__ __forceinline__ bool far_range(const double* __restrict__ omgs, int jw0, int jw1, const LineS<NI>& L) {
-  const double w0 = omgs[jw0], w1 = omgs[jw1];
+  return far_range_w<NI>(omgs[jw0], omgs[jw1], L);
+}
+// the same with the frequencies of the two ends in hand
+template <int NI>
+__device__ __forceinline__ bool far_range_w(double w0, double w1, const LineS<NI>& L) {
   const double d0 = w0 - L.wL, d1 = w1 - L.wL;
   const double kmax = ks_eval(w0, L.wpe2) + L.kL;
   const double dmin = fmin(fabs(d0), fabs(d1)) - kmax * fabs(L.Vd);
@@ -815,14 +821,16 @@ __device__ __forceinline__ void zero_lines(LineS<NI>& L) {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
 
+// sg (optional): sigmoid(x[s]) of the slots that have one, already evaluated by the caller (k_fused_finish needs them again
+// for the derivative of the activation)
 template <int NI>
 __device__ __forceinline__ void load_phys(const double* __restrict__ x, const double* __restrict__ scale,
                                           const double* __restrict__ shift, const uint8_t* __restrict__ sig,
-                                          const uint8_t* ti_same, bool activate, Phys<NI>& p) {
+                                          const uint8_t* ti_same, bool activate, Phys<NI>& p, const double* sg = nullptr) {
   auto tr = [&](int s) {
     const double v = x[s];
     if (!activate) return v;
-    return (sig[s] ? sigmoid(v) : v) * scale[s] + shift[s];
+    return (sig[s] ? (sg ? sg[s] : sigmoid(v)) : v) * scale[s] + shift[s];
   };
   p.Te = tr(TSFF_P_TE); p.ne = tr(TSFF_P_NE); p.m = tr(TSFF_P_M); p.lam = tr(TSFF_P_LAM);
   p.amp1 = tr(TSFF_P_AMP1); p.amp2 = tr(TSFF_P_AMP2); p.amp3 = tr(TSFF_P_AMP3);

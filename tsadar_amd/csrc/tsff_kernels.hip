@@ -69,6 +69,7 @@ struct KCall {
   double* sqdev[2];
   double* lpart;         // [B][3]
   double* gpart;         // [2][B][NP] per-feature gradient parts (interleaved plan)
+  double* lbrec;         // [items][4 wavefronts][kLBRec] lineout-scalar adjoints of k_spectrum_fused (finished by k_fused_finish)
   double wts[3];
   int B;
   int denom_mode;        // MODE 1 only: 0 constant denominators (folded into wts), 2: |data| + 1e-10 per sample
@@ -76,6 +77,8 @@ struct KCall {
 
 #include "k_tables.inc"
 #include "k_spectrum.inc"
+constexpr int kLineRec = 24;     // doubles per item of k_fused_prep's record: 9 + 4 n_ion lineout scalars + lam, amp1, amp2, amp3
+constexpr int kLBRec = 20;       // doubles per (item, wavefront) record of k_spectrum_fused: 9 + 3 n_ion sums + the two amplitude adjoints
 constexpr int kFusedMaxIon = 2;  // k_spectrum_fused is instantiated for n_ion <= 2 (4 x (7 + 3 n_ion) register accumulators per thread)
 #include "k_spectrum_fused.inc"
 #include "k_spectrum_rows.inc"
