@@ -318,6 +318,7 @@ def main():
     act_slots = [s for _, s in guess.slots.active_leaves]
     # the buffer of the step's one collective and one D2H copy: [3 | P x B_global], written by the gradient kernels
     packed = torch.zeros(3 + P * B * world, dtype=torch.float64, device=dev)
+    packed_ff = torch.zeros(3 + (P + eng.nvx) * B * world, dtype=torch.float64, device=dev) if args.free_form else None
 
     # (N > 1) one event pair per step around the all-reduce, on the stream the kernels run on: the first fires when this rank's
     # kernels are done, the second when the reduced buffer is back -- collective + waiting for the slowest rank
@@ -327,10 +328,12 @@ def main():
     def step():
         if args.forward_only:
             return eng.forward(X, batch["e_amps"], batch["i_amps"])
-        if args.free_form:  # (extra rows d loss / d f_e from a second kernel chain: packed by torch)
+        if args.free_form:  # (extra rows d loss / d f_e from a second kernel chain: packed by tsff_pack_fe_rows)
             gfe = eng.loss_grad(X, batch, w, gmask, fe=fe_dev, out=(terms, grad), want_fe_grad=True)[4]
-            g = torch.cat([grad[:, act].t(), gfe.t()]).contiguous()
-            return D.allreduce_loss_grad(terms, g, world, rank)
+            eng.pack_fe_rows(terms, grad, gfe, act_slots, B * world, rank * B, out=packed_ff)
+            if world > 1:
+                dist.all_reduce(packed_ff)
+            return packed_ff
         eng.loss_grad_packed(X, batch, w, gmask, act_slots, B * world, rank * B, out=packed)
         if world > 1:
             i = ar_i[0]

@@ -43,9 +43,10 @@
 extern "C" {
 #endif
 
-#define TSFF_ABI_VERSION 7
+#define TSFF_ABI_VERSION 8
 /* error codes (every entry point returns 0 or one of these; text via tsff_last_error):
  * -1 bad argument, -2 unsupported configuration / option, -3 not a differentiable leaf, -5 HIP runtime error,
+ * -22 stale or foreign token of saved projection records (tsff_form_factor_2d_grad),
  * TSFF_ERR_LDS: the configuration needs more LDS than a CU has (wide instrument functions at several points per pixel:
  * spectrum + halo + taps) -- the caller may retry with fewer IRF taps. */
 #define TSFF_ERR_LDS (-7)
@@ -212,11 +213,14 @@ int tsff_form_factor_2d_range(tsff_handle *h, int32_t feature, const double *phy
 
 /* tsff_form_factor_2d_range for ONE shared table (nv <= 256) that also keeps, in the handle, the projection record of
  * every point of the range (the projected distribution and the derivative sums of its rotation: proj2d_doubles(nv)
- * doubles per point): the adjoint that follows in a fit step (tsff_form_factor_2d_grad with use_saved != 0, same
- * feature / table size / point range, same phys and fe2d) then does no sampling of its own. */
+ * doubles per point): the adjoint that follows in a fit step (tsff_form_factor_2d_grad with saved_token = *token, same
+ * feature / table size / point range, same phys and fe2d) then does no sampling of its own.  *token (HOST pointer, never 0 on
+ * success) names this generation of records: a per-handle call counter mixed with the buffers, angles and range they were made
+ * from.  Only the token of the LAST save is valid, and any later 2-D forward on the handle invalidates it.  Precondition the
+ * token cannot check: the CONTENTS of phys / fe2d must not change between the save and the adjoint that presents its token. */
 int tsff_form_factor_2d_save(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
                              double ud_angle_deg, double va_angle_deg, int32_t B, int64_t point_begin,
-                             int64_t point_end, double *P);
+                             int64_t point_end, double *P, uint64_t *token);
 
 /* Adjoint of tsff_form_factor_2d for ONE shared table (the 2-D path is never batched in the reference): given
  * Pbar = d loss / d P (device, [B][G][npts][n_angles]) ->
@@ -226,11 +230,12 @@ int tsff_form_factor_2d_save(tsff_handle *h, int32_t feature, const double *phys
  *     weights scattered by LDS atomics, ghost cells folded back).
  * [point_begin, point_end) (point_end < 0: to the end): the contributions of that slice of the flat point list only --
  * both adjoints are sums over points, so the ranks of a node each take a slice and all-reduce the two outputs.
- * use_saved != 0: the projections come from the records of the preceding tsff_form_factor_2d_save (see there).
+ * saved_token != 0: the projections come from the records of the tsff_form_factor_2d_save that returned this token (see
+ * there); a stale or foreign token is refused with -22 (EINVAL), records made from other buffers / angles / range with -2.
  * Replaces what JAX reverse mode gives the reference for angular fits (inverse/loops.py:167-275). */
 int tsff_form_factor_2d_grad(tsff_handle *h, int32_t feature, const double *phys, const double *fe2d, int32_t nv,
                              double ud_angle_deg, double va_angle_deg, int32_t B, int64_t point_begin,
-                             int64_t point_end, int32_t use_saved, const double *Pbar, double *grad_phys,
+                             int64_t point_end, uint64_t saved_token, const double *Pbar, double *grad_phys,
                              double *grad_fe2d);
 
 /* Angular (ARTS) instrument chain for one image P[G][npts][n_angles] (device; from tsff_form_factor_2d or, for a 1-D
@@ -305,6 +310,14 @@ int tsff_loss_grad_fe(tsff_handle *h, const double *params, const double *fe, co
                       const double *e_amps, const double *i_amps, const double *noise_e, const double *noise_i, int32_t B,
                       const double *weights, const uint8_t *grad_mask, double *loss_terms, double *grad, double *grad_fe,
                       double *ThryE, double *ThryI);
+
+/* The packed buffer of a free-form f_e fit step from the outputs of tsff_loss_grad_fe (all device pointers):
+ * packed = [loss_terms[0..3) | rows x B_global], rows = the n_active scalar leaves (grad[b][active_slots[k]]) followed by the
+ * nvx values d loss / d fe[b][i] -- the ravel order of the optimiser's flat vector before the generator's chain rule (which
+ * stays on the host) --, this rank's columns [b_offset, b_offset + B) filled and every other column ZERO, so that the buffer
+ * is all-reduced in place like the one of tsff_loss_grad_packed (inverse/loops.py:40-54; form_factor.py:431-447 for the sharding). */
+int tsff_pack_fe_rows(tsff_handle *h, const double *loss_terms, const double *grad, const double *grad_fe, int32_t B,
+                      const int32_t *active_slots, int32_t n_active, int64_t B_global, int64_t b_offset, double *packed);
 
 /* LossFunction.array_loss: per-lineout masked sums with the theory spectrum as denominator
  * ((d-t)^2/t, loss_function.py:320-321).  sums [B][3] = S_iaw, S_blue, S_red per lineout;

@@ -1594,12 +1594,27 @@ def test_form_factor_2d_grad_finite_differences(torch_mod, nv, n_ion, G):
             sv = eng._saved_2d
             other = eng.dev(fe2.copy())
             gpx = torch.empty((B, eng.NP), dtype=torch.float64, device=eng.device)
-            rc = eng.lib.tsff_form_factor_2d_grad(eng.h, feature, eng._ptr(sv["phys_d"]), eng._ptr(other), nv, ud_ang, va_ang, B, 0, -1, 1,
+            rc = eng.lib.tsff_form_factor_2d_grad(eng.h, feature, eng._ptr(sv["phys_d"]), eng._ptr(other), nv, ud_ang, va_ang, B, 0, -1, sv["token"],
                                                   eng._ptr(eng.dev(Pbar)), eng._ptr(gpx), None)
-            assert rc != 0 and b"other inputs" in eng.lib.tsff_last_error(eng.h)
+            assert rc == -2 and b"other inputs" in eng.lib.tsff_last_error(eng.h)
+            # ... and a token that is not the one of the LAST save: a made-up one, and the previous generation's after a new save
+            assert sv["token"] != 0
+            rc = eng.lib.tsff_form_factor_2d_grad(eng.h, feature, eng._ptr(sv["phys_d"]), eng._ptr(sv["fe_d"]), nv, ud_ang, va_ang, B, 0, -1,
+                                                  sv["token"] ^ 0x10000, eng._ptr(eng.dev(Pbar)), eng._ptr(gpx), None)
+            assert rc == -22 and b"stale or foreign token" in eng.lib.tsff_last_error(eng.h)
+            old_token = sv["token"]
+            eng.form_factor_2d(feature, X, fe2, ud_ang, va_ang, save=True)
+            sv2 = eng._saved_2d
+            assert sv2["token"] not in (0, old_token)
+            rc = eng.lib.tsff_form_factor_2d_grad(eng.h, feature, eng._ptr(sv2["phys_d"]), eng._ptr(sv2["fe_d"]), nv, ud_ang, va_ang, B, 0, -1,
+                                                  old_token, eng._ptr(eng.dev(Pbar)), eng._ptr(gpx), None)
+            assert rc == -22
+            rc = eng.lib.tsff_form_factor_2d_grad(eng.h, feature, eng._ptr(sv2["phys_d"]), eng._ptr(sv2["fe_d"]), nv, ud_ang, va_ang, B, 0, -1,
+                                                  sv2["token"], eng._ptr(eng.dev(Pbar)), eng._ptr(gpx), None)
+            assert rc == 0 and np.allclose(gpx.cpu().numpy(), gp, rtol=1e-10, atol=0)
 
 
-@pytest.mark.parametrize("fe_type", ["arbitrary", "sphericalharmonic"])
+@pytest.mark.parametrize("fe_type", ["arbitrary", "sphericalharmonic", "sphericalharmonic-nn"])
 def test_angular_2d_vg_loss_adjoint(torch_mod, fe_type):
     """LossFunction.vg_loss for an ARTS deck with a 2-D distribution function: the gradient comes from the hand-written
     adjoint (loss seed -> tsff_ats_adjoint -> tsff_form_factor_2d_grad -> parameter transform / table generator) and is
@@ -1611,9 +1626,19 @@ def test_angular_2d_vg_loss_adjoint(torch_mod, fe_type):
 
     nvx = 48
     cfg = decks.deck_angular(2, nvx, (128, 256), 10, 110)
+    n_gen = 3
     if fe_type == "sphericalharmonic":
         cfg["parameters"]["electron"]["fe"] = {"active": True, "dim": 2, "type": "sphericalharmonic", "nvx": nvx, "params": {
             "flm_type": "mora-yahi", "init_m": 2.2, "LTx": 225000.0, "LTy": 400000.0, "Nl": 1, "nvr": 64}}
+    if fe_type == "sphericalharmonic-nn":   # FLM_NN radial functions (spherical_harmonics.py:14-50) with caller-supplied layer weights
+        rw = np.random.default_rng(8)
+        sizes = [1, 6, 6, 6, 1]
+        mk = lambda sc, b0: {"weights": [rw.normal(0, sc, (sizes[j + 1], sizes[j])) for j in range(4)],
+                             "biases": [rw.normal(0, 0.2, sizes[j + 1]) + (b0 if j == 3 else 0.0) for j in range(4)]}
+        cfg["parameters"]["electron"]["fe"] = {"active": True, "dim": 2, "type": "sphericalharmonic", "nvx": nvx, "params": {
+            "flm_type": "nn", "init_m": 2.2, "Nl": 1, "nvr": 64,
+            "nn_weights": {f"1,{m}": {"flm_mag": mk(0.6, 1.5), "flm_sign": mk(0.8, 0.0)} for m in (0, 1)}}}
+        n_gen = 2 * 2 * (6 + 36 + 36 + 6) + 1
     g = cfg["parameters"]["general"]
     for k, val in (("ud", 0.6), ("Va", -0.8)):
         g[k]["val"], g[k]["active"] = val, True
@@ -1635,7 +1660,7 @@ def test_angular_2d_vg_loss_adjoint(torch_mod, fe_type):
     assert ("electron", "fval" if fe_type == "arbitrary" else "fe") in names and ("general", "ud") in names
     diff, static = tree.partition(tp, spec)
     x0, loss_fn.unravel_weights = tree.ravel_pytree(diff)
-    assert x0.size == len(spec) - 1 + (nvx * nvx if fe_type == "arbitrary" else 3)
+    assert x0.size == len(spec) - 1 + (nvx * nvx if fe_type == "arbitrary" else n_gen)
     val, gflat = loss_fn.vg_loss(x0, static, batch)
     assert np.isfinite(val) and val > 0 and gflat.shape == x0.shape and np.all(np.isfinite(gflat))
     grads = diff.like(gflat)

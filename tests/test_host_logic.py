@@ -193,7 +193,7 @@ def test_spherical_harmonics_generator():
     assert ga.shape == (2 * 2 * 32 + 1,) and np.max(np.abs(ga - gfd)) < 1e-7 * np.max(np.abs(gfd))
     np.testing.assert_array_equal(sh3.get_params(), th)                  # the generator is left untouched
     assert np.max(np.abs(sh.vjp(fbar.repeat(2, 0).repeat(2, 1)) - sh._vjp_fd(fbar.repeat(2, 0).repeat(2, 1)))) == 0.0  # Mora-Yahi: FD
-    dc2["params"]["flm_type"] = "nn"
+    dc2["params"]["flm_type"] = "no-such-model"
     with pytest.raises(NotImplementedError):
         D.SphericalHarmonics(dc2)
     cfg = decks.deck_angular(2, 128)
@@ -235,3 +235,69 @@ def test_arbitrary_1v_generator_and_ravel_order():
     np.testing.assert_array_equal(back.fval, tp.fval)
     fitted, n = tp.get_fitted_params(cfg["parameters"])
     assert "f" in fitted["electron"] and n == 4
+
+
+def test_spherical_harmonics_nn_radial_functions():
+    """flm_type "nn" (FLM_NN, spherical_harmonics.py:14-50): two MLPs per harmonic over the radial axis with caller-supplied layer
+    weights.  Forward against a torch twin of the reference's expression, the hand-written backward pass (MLP.backward chained
+    through 10^-a, the radial interpolation, the floor and the normalisation) against torch autograd of that twin."""
+    import torch
+
+    nvx, nvr, width, depth = 32, 24, 8, 3
+    rng = np.random.default_rng(3)
+    sizes = [1] + [width] * depth + [1]
+    mk = lambda scale: {"weights": [rng.normal(0, scale, (sizes[j + 1], sizes[j])) for j in range(depth + 1)],
+                        "biases": [rng.normal(0, 0.3, sizes[j + 1]) for j in range(depth + 1)]}
+    nn_w = {f"1,{m}": {"flm_mag": mk(0.7), "flm_sign": mk(0.9)} for m in (0, 1)}
+    dc = {"nvx": nvx, "dim": 2, "type": "sphericalharmonic", "active": True,
+          "params": {"flm_type": "nn", "init_m": 2.4, "Nl": 1, "nvr": nvr, "nn_weights": nn_w}}
+    sh = D.SphericalHarmonics(dc)
+    theta = sh.get_params()
+    nW = sum(w.size for w in nn_w["1,0"]["flm_mag"]["weights"])
+    assert theta.size == 2 * 2 * nW + 1 and nW == width + 2 * width * width + width
+    np.testing.assert_array_equal(theta[:width], nn_w["1,0"]["flm_mag"]["weights"][0].ravel())   # flm_mag first, layer by layer
+    f = sh()
+    dv = sh.vx[1] - sh.vx[0]
+    assert abs(np.sum(f) * dv * dv - 1.0) < 1e-13 and np.abs(f - f[:, ::-1]).max() > 1e-6 * f.max()
+
+    # torch twin of SphericalHarmonics.__call__ with FLM_NN radial functions (spherical_harmonics.py:42-50, 300-318)
+    T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    vr, f00 = T(sh.vr), T(sh.get_f00())
+    leaves = []
+
+    def mlp(spec, final):
+        h = vr[:, None]
+        for j, (W, b) in enumerate(zip(spec["weights"], spec["biases"])):
+            Wt = T(W).requires_grad_(True)
+            leaves.append(Wt)
+            z = h @ Wt.T + T(b)
+            h = torch.relu(z) if (j < depth or final == "relu") else torch.tanh(z)
+        return h[:, 0]
+
+    def interp(x, xp, fp, right):   # np.interp with a constant to the right of the last node
+        i = np.clip(np.searchsorted(xp, x, side="right") - 1, 0, xp.size - 2)
+        t = T(np.clip((x - xp[i]) / (xp[i + 1] - xp[i]), 0.0, 1.0))
+        v = fp[i] * (1 - t) + fp[i + 1] * t
+        return torch.where(T(x) <= xp[-1], v, torch.full_like(v, right))
+
+    q = sh.vr_vxvy.ravel()
+    ft = interp(q, sh.vr, f00, 1e-16)
+    for m in (0, 1):
+        spec = nn_w[f"1,{m}"]
+        flm = f00 * 10.0 ** (-mlp(spec["flm_mag"], "relu")) * mlp(spec["flm_sign"], "tanh")
+        ft = ft + interp(q, sh.vr, flm, 1e-32) * T(D.real_sph_harm(1, m, sh.phi, sh.th).ravel())
+    ft = torch.clamp(ft, min=1e-32)
+    ft = (ft / (ft.sum() * dv * dv)).reshape(nvx, nvx)
+    np.testing.assert_allclose(f, ft.detach().numpy(), rtol=1e-12, atol=1e-300)
+    fbar = rng.standard_normal((nvx, nvx))
+    (ft * T(fbar)).sum().backward()
+    ref = np.concatenate([w.grad.numpy().ravel() for w in leaves])
+    ga = sh.vjp(fbar)
+    assert np.max(np.abs(ga[:-1] - ref)) < 1e-10 * np.max(np.abs(ref))
+    gfd = sh._vjp_fd(fbar)
+    assert abs(ga[-1] - gfd[-1]) < 1e-6 * max(abs(gfd[-1]), 1e-12) and np.max(np.abs(ga[:-1] - gfd[:-1])) < 1e-6 * np.max(np.abs(ref))
+    np.testing.assert_array_equal(sh.get_params(), theta)
+    # without supplied weights: a documented NumPy initialisation (not the reference's PRNGKey numbers), the reference's layer sizes
+    dc["params"].pop("nn_weights")
+    sh2 = D.SphericalHarmonics(dc)
+    assert sh2.get_params().size == 2 * 2 * (32 + 2 * 32 * 32 + 32) + 1 and np.isfinite(sh2()).all()

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsff.so")
 LIB_PATH = os.environ.get("TSFF_LIBRARY", LIB_PATH)  # A/B experiments: another in-tree build of the same ABI
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_ION = 4
 NBINS = 1024
 NXI1 = 1024
@@ -113,8 +113,9 @@ _SIGNATURES = {
     "tsff_form_factor_2d": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, _vp]),
     "tsff_form_factor_2d_range": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32,
                                             C.c_int64, C.c_int64, _vp]),
-    "tsff_form_factor_2d_grad": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp]),
-    "tsff_form_factor_2d_save": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_int64, _vp]),
+    "tsff_form_factor_2d_grad": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_int64, C.c_uint64, _vp, _vp, _vp]),
+    "tsff_form_factor_2d_save": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_int64, _vp,
+                                           C.POINTER(C.c_uint64)]),
     "tsff_ats_setup": (C.c_int, [_vp, C.POINTER(TsffAtsConfig)]),
     "tsff_ats_spectrum": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),
     "tsff_ats_adjoint": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, c_double_p]),
@@ -123,6 +124,7 @@ _SIGNATURES = {
     "tsff_loss_grad_packed": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64,
                                         _vp, _vp, _vp]),
     "tsff_loss_grad_fe": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, c_double_p, c_uint8_p, _vp, _vp, _vp, _vp, _vp]),
+    "tsff_pack_fe_rows": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64, _vp]),
     "tsff_array_loss": (C.c_int, [_vp] + [_vp] * 8 + [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "tsff_enable_timing": (C.c_int, [_vp, C.c_int32]),
     "tsff_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),

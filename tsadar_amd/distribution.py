@@ -125,6 +125,62 @@ def real_sph_harm(l: int, m: int, azimuth: np.ndarray, polar: np.ndarray) -> np.
     return norm * _assoc_legendre(l, m, np.cos(polar)) * np.cos(m * azimuth)
 
 
+class MLP:
+    """eqx.nn.MLP(in_size=1, out_size=1, width_size, depth) as the reference's FLM_NN builds it (spherical_harmonics.py:37-38):
+    ``depth`` hidden Linear layers of ``width`` units plus the output layer, relu between the layers, ``final`` ("relu" / "tanh")
+    after the last, evaluated at every node of a 1-D axis.  Weights are caller-supplied (``weights[j]`` [out, in],
+    ``biases[j]`` [out]); the trainable leaves are the WEIGHTS only, as in the reference's filter spec (base.py:503-516).
+    ``backward`` is the hand-written reverse pass: d loss / d output[n] -> d loss / d weights[j]."""
+
+    def __init__(self, weights, biases, final: str):
+        self.W = [np.array(w, dtype=np.float64) for w in weights]
+        self.b = [np.array(b, dtype=np.float64).reshape(-1) for b in biases]
+        assert len(self.W) == len(self.b) and self.W[0].shape[1] == 1 and self.W[-1].shape[0] == 1
+        for j in range(len(self.W)):
+            assert self.W[j].shape[0] == self.b[j].size and (j == 0 or self.W[j].shape[1] == self.W[j - 1].shape[0])
+        assert final in ("relu", "tanh")
+        self.final = final
+
+    @staticmethod
+    def default(width: int, depth: int, final: str, seed: int):
+        """Deterministic NumPy initialisation, uniform(-1/sqrt(in), 1/sqrt(in)) like equinox's Linear -- NOT the reference's numbers:
+        those come from jax.random.PRNGKey(0) / (42), which cannot be reproduced without JAX.  Pass the weights of a reference
+        run through ``params["nn_weights"]`` to continue from them."""
+        rng = np.random.default_rng(seed)
+        sizes = [1] + [width] * depth + [1]
+        W = [rng.uniform(-1, 1, (sizes[j + 1], sizes[j])) / np.sqrt(sizes[j]) for j in range(len(sizes) - 1)]
+        b = [rng.uniform(-1, 1, sizes[j + 1]) / np.sqrt(sizes[j]) for j in range(len(sizes) - 1)]
+        return MLP(W, b, final)
+
+    def forward(self, x: np.ndarray, keep: bool = False) -> np.ndarray:
+        h = np.asarray(x, dtype=np.float64).reshape(-1, 1)   # [n, 1]
+        acts, pre = [h], []
+        for j, (W, b) in enumerate(zip(self.W, self.b)):
+            z = h @ W.T + b
+            pre.append(z)
+            last = j == len(self.W) - 1
+            h = (np.maximum(z, 0.0) if (not last or self.final == "relu") else np.tanh(z))
+            acts.append(h)
+        if keep:
+            self._acts, self._pre = acts, pre
+        return h[:, 0]
+
+    def backward(self, out_bar: np.ndarray):
+        """out_bar [n] = d loss / d forward(x)[n] (of the LAST forward(keep=True)) -> [d loss / d W_j]."""
+        g = np.asarray(out_bar, dtype=np.float64).reshape(-1, 1)
+        grads = [None] * len(self.W)
+        for j in range(len(self.W) - 1, -1, -1):
+            z, a_in = self._pre[j], self._acts[j]
+            last = j == len(self.W) - 1
+            dz = g * ((z > 0.0) if (not last or self.final == "relu") else (1.0 - np.tanh(z) ** 2))
+            grads[j] = dz.T @ a_in
+            g = dz @ self.W[j]
+        return grads
+
+    def n_weights(self) -> int:
+        return int(sum(w.size for w in self.W))
+
+
 class SphericalHarmonics:
     """Host mirror of the reference class: ``__call__()`` -> f_e[nvx, nvx]; ``vx``; ``get_unnormed_params()``."""
 
@@ -155,18 +211,33 @@ class SphericalHarmonics:
                 elif self.flm_type == "arbitrary":
                     self.flm[(l, m)] = {"flm_sign": np.zeros(nvr), "flm_mag": np.zeros(nvr)}
                 elif self.flm_type == "nn":
-                    raise NotImplementedError("flm_type 'nn' (equinox MLP radial functions) is not built")
+                    # FLM_NN (spherical_harmonics.py:14-50): two MLPs per harmonic over the radial axis, magnitude (relu end,
+                    # -> f00 10^-out) and sign (tanh end).  Layer weights and biases come from the deck (params["nn_weights"]
+                    # ["l,m"] = {"flm_mag": {"weights": [...], "biases": [...]}, "flm_sign": {...}}) or, absent that, from a
+                    # documented NumPy initialisation (MLP.default): the reference's PRNGKey(0) / (42) numbers need JAX.
+                    given = (p.get("nn_weights") or {}).get(f"{l},{m}")
+                    nets = {}
+                    for k, (name, final, seed) in enumerate((("flm_mag", "relu", 0), ("flm_sign", "tanh", 42))):
+                        if given is not None:
+                            nets[name] = MLP(given[name]["weights"], given[name]["biases"], final)
+                        else:
+                            nets[name] = MLP.default(int(p.get("nn_width", 32)), int(p.get("nn_depth", 3)), final, seed + 1000 * (l * 10 + m))
+                    self.flm[(l, m)] = nets
                 else:
                     raise NotImplementedError(f"Unknown flm_type: {p.get('flm_type')}")
 
     # trainable leaves in the reference's pytree order (get_distribution_filter_spec, base.py:484-523): the radial
     # functions of every harmonic (log_10_LT for Mora-Yahi; flm_sign then flm_mag for the free radial functions), then
     # normed_m
+    # (flm_type "nn": the layer weights of flm_mag, then of flm_sign -- the field order of FLM_NN --, biases are static)
     def get_params(self) -> np.ndarray:
         parts = []
         for key in sorted(self.flm):
             prm = self.flm[key]
-            parts += [np.atleast_1d(prm["log_10_LT"])] if self.flm_type == "mora-yahi" else [prm["flm_sign"], prm["flm_mag"]]
+            if self.flm_type == "nn":
+                parts += [w.ravel() for name in ("flm_mag", "flm_sign") for w in prm[name].W]
+            else:
+                parts += [np.atleast_1d(prm["log_10_LT"])] if self.flm_type == "mora-yahi" else [prm["flm_sign"], prm["flm_mag"]]
         return np.concatenate(parts + [np.atleast_1d(self.normed_m)]).astype(np.float64)
 
     def set_params(self, vec) -> None:
@@ -176,6 +247,10 @@ class SphericalHarmonics:
             prm = self.flm[key]
             if self.flm_type == "mora-yahi":
                 prm["log_10_LT"] = float(vec[o]); o += 1
+            elif self.flm_type == "nn":
+                for name in ("flm_mag", "flm_sign"):
+                    for j, w in enumerate(prm[name].W):
+                        prm[name].W[j] = vec[o : o + w.size].reshape(w.shape).copy(); o += w.size
             else:
                 n = self.vr.size
                 prm["flm_sign"] = vec[o : o + n].copy(); o += n
@@ -187,6 +262,8 @@ class SphericalHarmonics:
         harmonic) are chained analytically -- normalisation, floor, radial interpolation (transposed), 10^mag * sign,
         sigmoid / tanh, smoothing (transposed) --; the super-Gaussian order of f00 and the Mora-Yahi gradient lengths (one
         scalar each) by central differences of the generator."""
+        if self.flm_type == "nn":
+            return self._vjp_nn(fe_bar, step)
         if self.flm_type != "arbitrary":
             return self._vjp_fd(fe_bar, step)
         theta = self.get_params()
@@ -233,6 +310,46 @@ class SphericalHarmonics:
         out[-1] = np.sum(fe_bar * (vals[0] - vals[1])) / (2.0 * step)
         return out
 
+    def _vjp_nn(self, fe_bar: np.ndarray, step: float = 1e-6) -> np.ndarray:
+        """flm_type "nn": normalisation, floor and the transposed radial interpolation as for the free radial functions, then
+        flm = f00 10^(-a) s with a = flm_mag(vr) (relu end), s = flm_sign(vr) (tanh end): the hand-written backward pass of the
+        two MLPs (MLP.backward) gives d loss / d layer weights; the order of f00 (one scalar) by central differences."""
+        theta = self.get_params()
+        out = np.zeros_like(theta)
+        f00 = self.get_f00()
+        nvr = self.vr.size
+        f = np.interp(self.vr_vxvy, self.vr, f00, right=1e-16)
+        fw = {}
+        for key in sorted(self.flm):
+            a = self.flm[key]["flm_mag"].forward(self.vr, keep=True)
+            sg = self.flm[key]["flm_sign"].forward(self.vr, keep=True)
+            mag = f00 * 10.0 ** (-a)
+            fw[key] = (mag, sg)
+            f = f + np.interp(self.vr_vxvy, self.vr, mag * sg, right=1e-32) * real_sph_harm(key[0], key[1], self.phi, self.th)
+        live = f > 1e-32
+        fc = np.maximum(f, 1e-32)
+        tot, c = np.sum(fc), 1.0 / (self.vx[1] - self.vx[0]) ** 2
+        f_bar = c * (fe_bar / tot - np.sum(fe_bar * fc) / tot**2) * live
+        q = self.vr_vxvy.ravel()
+        i = np.clip(np.searchsorted(self.vr, q, side="right") - 1, 0, nvr - 2)
+        t = np.clip((q - self.vr[i]) / (self.vr[i + 1] - self.vr[i]), 0.0, 1.0)
+        inside = q <= self.vr[-1]
+        o = 0
+        for key in sorted(self.flm):
+            g = (f_bar * real_sph_harm(key[0], key[1], self.phi, self.th)).ravel() * inside
+            r_bar = np.bincount(i, weights=g * (1.0 - t), minlength=nvr) + np.bincount(i + 1, weights=g * t, minlength=nvr)
+            mag, sg = fw[key]
+            for name, seed in (("flm_mag", r_bar * sg * mag * (-np.log(10.0))), ("flm_sign", r_bar * mag)):
+                for gw in self.flm[key][name].backward(seed):
+                    out[o : o + gw.size] = gw.ravel(); o += gw.size
+        vals = []
+        for sgn in (+1.0, -1.0):
+            self.normed_m = theta[-1] + sgn * step
+            vals.append(self())
+        self.normed_m = theta[-1]
+        out[-1] = np.sum(fe_bar * (vals[0] - vals[1])) / (2.0 * step)
+        return out
+
     def _vjp_fd(self, fe_bar: np.ndarray, step: float = 1e-6) -> np.ndarray:
         """Central differences of the generator, 2 evaluations per parameter (cross-check of vjp; Mora-Yahi)."""
         theta = self.get_params()
@@ -265,6 +382,8 @@ class SphericalHarmonics:
             lam_v = (self.vr / ve) ** 4.0
             coeff = (mf / 2 * self.vr**mf - 5 * mf / 12 * gamma(8 / mf) / gamma(6 / mf) * self.vr ** (mf - 2) - 1.5) * lam_v
             return coeff / 10 ** prm["log_10_LT"] * f00
+        if self.flm_type == "nn":   # FLM_NN.__call__ (spherical_harmonics.py:42-50)
+            return f00 * 10.0 ** (-prm["flm_mag"].forward(self.vr)) * prm["flm_sign"].forward(self.vr)
         nvr = self.vr.size  # ArbitraryVr.__call__
         w = np.hanning(nvr // 4)
         w = w / w.sum()

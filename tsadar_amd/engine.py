@@ -393,12 +393,13 @@ class Engine:
         lo, hi = point_range if point_range is not None else (0, -1)
         self._sync_stream()
         if save and shared and nv <= 256:   # keep the projection records for form_factor_2d_grad(use_saved=True)
+            token = C.c_uint64(0)
             rc = self.lib.tsff_form_factor_2d_save(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, float(ud_angle),
-                                                   float(va_angle), B, int(lo), int(hi), self._ptr(P))
+                                                   float(va_angle), B, int(lo), int(hi), self._ptr(P), C.byref(token))
             # the library ties the records to the buffers they were made from: keep those buffers (and what the caller
             # passed) so that the adjoint can present the very same ones
             keep = lambda a: a if isinstance(a, torch.Tensor) else np.array(a, dtype=np.float64, copy=True)
-            self._saved_2d = dict(phys_in=keep(phys), fe_in=keep(fe2d), phys_d=phys_d, fe_d=fe_d)
+            self._saved_2d = dict(phys_in=keep(phys), fe_in=keep(fe2d), phys_d=phys_d, fe_d=fe_d, token=int(token.value))
         else:
             self._saved_2d = None
             rc = self.lib.tsff_form_factor_2d_range(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, int(shared),
@@ -407,7 +408,7 @@ class Engine:
         return P
 
     def form_factor_2d_grad(self, feature, phys, fe2d, Pbar, ud_angle=0.0, va_angle=0.0, want_table=True, point_range=None,
-                            use_saved=False):
+                            use_saved=False, saved_token=None):
         """Adjoint of form_factor_2d (one shared table): Pbar [B, G, npts, n_angles] ->
         (grad_phys [B, NP], grad_fe2d [nv, nv] or None) as device tensors.  ``point_range = (begin, end)``: the
         contributions of that slice of the flat point list only (to be summed over the ranks of a node)."""
@@ -427,7 +428,8 @@ class Engine:
         self._sync_stream()
         lo, hi = point_range if point_range is not None else (0, -1)
         rc = self.lib.tsff_form_factor_2d_grad(self.h, int(feature), self._ptr(phys_d), self._ptr(fe_d), nv, float(ud_angle),
-                                               float(va_angle), B, int(lo), int(hi), int(saved is not None),
+                                               float(va_angle), B, int(lo), int(hi),
+                                               C.c_uint64(int(saved_token) if saved_token is not None else (saved["token"] if saved is not None else 0)),
                                                self._ptr(Pb), self._ptr(gp), self._ptr(gf))
         L.check(self.lib, self.h, rc)
         return gp, gf
@@ -568,6 +570,22 @@ class Engine:
                                      gm.ctypes.data_as(L.c_uint8_p), self._ptr(terms), self._ptr(grad), self._ptr(E), self._ptr(I))
         L.check(self.lib, self.h, rc)
         return terms, grad, E, I
+
+    def pack_fe_rows(self, terms, grad, gfe, active_slots, B_global=None, b_offset=0, out=None):
+        """The packed buffer ``[3 | (P + nvx) x B_global]`` of a free-form f_e step from the outputs of ``loss_grad(want_fe_grad=True)``
+        (tsff_pack_fe_rows: one transposing kernel, this rank's columns filled, the others zero)."""
+        torch = self.torch
+        B = int(grad.shape[0])
+        Bg = B if B_global is None else int(B_global)
+        act = np.ascontiguousarray(active_slots, dtype=np.int32)
+        n = 3 + (act.size + self.nvx) * Bg
+        packed = out if out is not None else torch.empty(n, dtype=torch.float64, device=self.device)
+        assert packed.numel() == n
+        self._sync_stream()
+        L.check(self.lib, self.h, self.lib.tsff_pack_fe_rows(self.h, self._ptr(terms), self._ptr(grad), self._ptr(gfe), B,
+                                                             act.ctypes.data_as(C.POINTER(C.c_int32)), int(act.size), Bg, int(b_offset),
+                                                             self._ptr(packed)))
+        return packed
 
     def loss_grad_packed(self, params, batch, weights, grad_mask, active_slots, B_global=None, b_offset=0, want_spectra=False, out=None):
         """tsff_loss_grad_packed: -> (packed [3 + P * B_global] CUDA tensor, ThryE, ThryI).  packed = [S_iaw, S_blue, S_red |

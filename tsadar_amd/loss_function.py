@@ -319,8 +319,16 @@ class LossFunction:
         if ts_params.fval is not None and ts_params.slots.fval_active:
             # free-form f_e: nvx more rows (d loss / d fe, chained on the host); packed by torch, one all-reduce all the same
             eng, w, terms, grad, E, I = self._evaluate(ts_params, batch, want_spectra=not lbfgs, B_global=Bg)
-            gact = torch.cat([grad[:, act].t(), self._gfe.t()]).contiguous()  # [P + nvx, B_local], ravel order
-            out = D.allreduce_loss_grad(terms, gact, world, rank, self.pg, B_global=Bg, b_offset=lo)
+            if hasattr(eng, "pack_fe_rows") and grad.shape[0] > 0:
+                # [3 | (P + nvx) x B_global] in ravel order, this rank's columns filled, by one transposing kernel (tsff_pack_fe_rows)
+                out = eng.pack_fe_rows(terms, grad, self._gfe, act, Bg, lo)
+                if world > 1:
+                    import torch.distributed as dist
+
+                    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.pg)
+            else:   # (an empty shard, or the CPU rehearsal of the distributed tests: the torch form of the same buffer)
+                gact = torch.cat([grad[:, act].t(), self._gfe.t()]).contiguous()  # [P + nvx, B_local], ravel order
+                out = D.allreduce_loss_grad(terms, gact, world, rank, self.pg, B_global=Bg, b_offset=lo)
             host = eng.download(out)
             flat = self._chain_fval(host[3:], len(act), diff_global)
         else:
