@@ -420,7 +420,7 @@ def main():
     # issue-slot utilisation of the VALU from the committed SQ counters of this very kernel and workload (rocprofv3 --pmc cannot run
     # inside bench.py): SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles) -- NOT the algorithmic-flop fraction next to it
     issue = None
-    kname = "k_spectrum<1, 0, 0" if args.forward_only else "k_spectrum_fused<1, 0"
+    kname = "k_forward_pairs<1" if args.forward_only else "k_spectrum_fused<1, 0"
     if not variant and args.ppp == 1 and args.nvx == 128 and not (args.plan & 2):
         for cf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")), reverse=True):
             cj = json.load(open(cf))
@@ -472,9 +472,10 @@ def main():
             "traffic": traffic,
             "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % (os.path.basename(tfile) if tfile else "-"),
             "algorithmic_bytes_per_launch": B * abytes,
-            "kernel": ("k_spectrum<1,0,0,256,*> (forward only)" if args.forward_only else
+            "kernel": (("k_forward_pairs<1,*,2,1> (512 threads per item: one dispatch round)" if 2 * B <= 512 else
+                        "k_fused_prep + k_forward_pairs<1,*,1,2> (256 threads per item)") if args.forward_only else
                        ("k_spectrum<1,1,2,256,false> (two-sweep kernel with table adjoints)" if args.free_form else
-                        ("k_spectrum_fused<1,%d,false> (one launch of 2B 256-thread workgroups, one sweep over the points)" % (1 if args.dlm else 0)
+                        ("k_fused_prep + k_spectrum_fused<1,%d,*> (2B 256-thread workgroups, one sweep over the points); k_fused_finish behind it" % (1 if args.dlm else 0)
                          if args.ppp == 1 else
                          "k_spectrum_rows<1,%d> (points_per_pixel %d: one sweep in rounds of 1024 samples, Jacobian rows in a global scratch array)" % (1 if args.dlm else 0, args.ppp)))
                        if not (args.plan & 2) else "k_spectrum<1,1,GM,256,false> (two-sweep kernel)"),

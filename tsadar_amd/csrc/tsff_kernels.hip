@@ -81,6 +81,7 @@ constexpr int kLineRec = 24;     // doubles per item of k_fused_prep's record: 9
 constexpr int kLBRec = 20;       // doubles per (item, wavefront) record of k_spectrum_fused: 9 + 3 n_ion sums + the two amplitude adjoints
 constexpr int kFusedMaxIon = 2;  // k_spectrum_fused is instantiated for n_ion <= 2 (4 x (7 + 3 n_ion) register accumulators per thread)
 #include "k_spectrum_fused.inc"
+#include "k_forward.inc"
 #include "k_spectrum_rows.inc"
 #include "k_form_factor.inc"
 #include "k_form_factor_2d.inc"
