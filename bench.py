@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--irf-cutoff", type=float, default=12.0,
                     help="IRF taps kept within this many standard deviations (engine default 12: the reference's full-length convolution to the "
                          "last bit of a spectrum's 1e-22 tails; 8: differences below 1e-14 of the spectrum's maximum; not the headline setting)")
+    ap.add_argument("--dlm-blocks", type=int, default=-1, help="--dlm: column blocks of the pipelined step (TSFF_OPT_DLM_BLOCKS; 1 = one stream)")
     ap.add_argument("--plan", type=int, default=0, help="launch plan bit mask (experiments): 0 automatic, 1 never interleave the features, 2 two-sweep kernel instead of the one-sweep one")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -295,6 +296,8 @@ def main():
 
     if args.plan:
         eng.set_launch_plan(args.plan)
+    if args.dlm_blocks >= 0:
+        eng.set_dlm_blocks(args.dlm_blocks)
     # synthetic inputs: each rank draws its own shard (seed offset by rank), data generated on the GPU
     rng = np.random.default_rng(S.SEED + rank)
     truth = S.draw_params(cfg, B, rng, dlm=args.dlm)

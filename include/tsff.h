@@ -167,8 +167,14 @@ int tsff_set_stream(tsff_handle *h, void *hip_stream);
  * two-sweep kernel; bit 2: never three forward-only workgroups per CU (tsff_forward runs three 256-thread workgroups per CU when
  * the batch is large enough to need them); bit 3: the one-sweep kernel evaluates every base point itself instead of taking its pair's
  * right neighbour from the next lane; bit 5 (32): the per-lineout W tables by the 128 x 128-tiled GEMM instead of the 128 x 144 one (bit 4 is
- * unused and refused).  The spectra are identical either way; the gradient differs by rounding. */
-enum { TSFF_OPT_DENOM_MODE = 1, TSFF_OPT_LAUNCH_PLAN = 2 };
+ * unused and refused).  The spectra are identical either way; the gradient differs by rounding.
+ * TSFF_OPT_DLM_BLOCKS (experimental, default off): tsff_loss_grad(_packed) with fe_mode TSFF_FE_DLM and the DLM order among the
+ * differentiated leaves builds the per-lineout tables (k_fe_vectors + the FP64-MFMA GEMM) in n column blocks of the batch on a second
+ * stream owned by the handle (non-blocking, higher priority) while the one-sweep kernel works on the previous block on the handle's
+ * stream; the call still returns with everything ordered on the handle's stream (fork / join by events).  0 / 1: off (one stream),
+ * n: n blocks (rounded to multiples of 256 lineouts).  Same bits either way.  On gfx950 it is slower than one stream (the FP64 matrix
+ * and vector instructions share one datapath: DESIGN.md section 4.2), which is why it is off. */
+enum { TSFF_OPT_DENOM_MODE = 1, TSFF_OPT_LAUNCH_PLAN = 2, TSFF_OPT_DLM_BLOCKS = 3 };
 int tsff_set_option(tsff_handle *h, int32_t key, int32_t value);
 /* make sure the workspace holds B lineouts (calls grow it lazily; not inside graph capture) */
 int tsff_reserve(tsff_handle *h, int32_t B);

@@ -263,6 +263,34 @@ def test_gradient_dlm_order(torch_mod, nvx):
         assert np.max(np.abs(G[k] - ref[k])) / scale < 1e-7, (k, G[k], ref[k])
 
 
+def test_dlm_step_in_column_blocks_is_bit_identical(torch_mod):
+    """TSFF_OPT_DLM_BLOCKS: the per-lineout tables built block by block on the handle's second stream and the one-sweep kernel
+    launched per block (offset b0 into batch-global records) give the bits of the one-stream step -- loss sums, gradient, spectra --
+    with a ragged last block (B = 600 -> blocks of 256, 256, 88), through both output forms, call after call."""
+    B = 600
+    cfg = decks.deck_fit(active=("Te", "ne", "m", "amp1", "amp2", "lam"))
+    cfg["parameters"]["electron"]["fe"]["params"]["m"]["val"] = 2.7
+    sa = util.sa_fit(B)
+    batch = util.synthetic_batch(cfg, sa, B, seed=5)
+    normed = util.random_lineouts(cfg, B, seed=6, ranges=dict(m=(2.05, 4.4)))
+    i_norm, e_norm = orc.loss_norms(cfg, batch)
+    eng = _engine(cfg, sa)
+    w = eng.loss_weights(B, i_norm, e_norm, cfg["data"]["ion_loss_scale"])
+    x = util.normed_to_matrix(normed, 1)
+    gm = eng.slots.active.astype(np.uint8)
+    ref = [t.cpu().numpy() for t in eng.loss_grad(x, batch, w, gm, want_spectra=True)]
+    assert np.all(ref[1][:, 2] != 0.0)   # (slot TSFF_P_M: the DLM order is a leaf of every lineout)
+    for nblk in (3, 2, 3):
+        eng.set_dlm_blocks(nblk)
+        got = [t.cpu().numpy() for t in eng.loss_grad(x, batch, w, gm, want_spectra=True)]
+        for a, b_ in zip(ref, got):
+            assert np.array_equal(a, b_), nblk
+    eng.set_dlm_blocks(1)
+    got = [t.cpu().numpy() for t in eng.loss_grad(x, batch, w, gm, want_spectra=True)]
+    for a, b_ in zip(ref, got):
+        assert np.array_equal(a, b_)
+
+
 def test_per_lineout_tables_match_log_sum(torch_mod):
     """The matrix-vector form of the W table (k_fe_vectors + k_wgemm, per-lineout f_e) equals the direct
     1640 x 1022 logarithm sum (k_fe_prepare) and the oracle: forward with explicit per-lineout f_e."""

@@ -27,6 +27,7 @@ LOSS_METHODS = {"l2": 0, "l1": 1, "log-cosh": 2, "poisson": 3}
 FEATURE_ELE, FEATURE_ION = 0, 1
 OPT_DENOM_MODE = 1
 OPT_LAUNCH_PLAN = 2
+OPT_DLM_BLOCKS = 3
 ERR_LDS = -7  # TSFF_ERR_LDS: more LDS needed than a CU has
 
 

@@ -73,6 +73,9 @@ struct KCall {
   double wts[3];
   int B;
   int denom_mode;        // MODE 1 only: 0 constant denominators (folded into wts), 2: |data| + 1e-10 per sample
+  // k_spectrum_fused launched per column block of the batch (the pipelined DLM plan, launch_fused): this launch covers lineouts
+  // [b0, b0 + B) of a batch of Btot; every per-lineout pointer above stays batch-global.  One launch over the whole batch: b0 = 0, Btot = B.
+  int b0, Btot;
 };
 
 #include "k_tables.inc"

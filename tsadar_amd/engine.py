@@ -651,6 +651,11 @@ class Engine:
         bit 1: always the two-sweep kernel; bit 2: never three forward-only workgroups per CU."""
         L.check(self.lib, self.h, self.lib.tsff_set_option(self.h, L.OPT_LAUNCH_PLAN, int(plan)))
 
+    def set_dlm_blocks(self, n: int):
+        """TSFF_OPT_DLM_BLOCKS: column blocks of the pipelined DLM step (per-lineout tables of block i + 1 on a second stream while
+        the one-sweep kernel works on block i).  0 / 1: off (default: measured slower on gfx950), n: n blocks.  Same bits."""
+        L.check(self.lib, self.h, self.lib.tsff_set_option(self.h, L.OPT_DLM_BLOCKS, int(n)))
+
     def fp64_fma_peak_tflops(self) -> float:
         """Measured FP64 vector FMA rate of this device (micro-benchmark, TFLOP/s)."""
         v = C.c_double()
