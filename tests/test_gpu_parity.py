@@ -1913,7 +1913,7 @@ def test_config4_point_ranges_are_bit_identical(torch_mod, config4):
 
 def test_config4_adjoint_saved_records_and_finite_differences(torch_mod, config4):
     """(iii) the fit-loop form (forward keeps the projection records, adjoint does no sampling) == the plain adjoint to
-    1e-11 with the table adjoint cut in 4 tiles of 128 x 128 cells; (iv) d <Pbar, P> / d fe2d[i][j] against central
+    1e-13 (parameters 1e-14) with the table adjoint cut in 4 tiles of 128 x 128 cells; (iv) d <Pbar, P> / d fe2d[i][j] against central
     differences of the forward on 5 entries (2e-5, as at the smaller sizes)."""
     torch = torch_mod
     c = config4
@@ -1927,8 +1927,11 @@ def test_config4_adjoint_saved_records_and_finite_differences(torch_mod, config4
     gp3, gf3 = eng.form_factor_2d_grad(0, X, fe2, Pbar, c["ud"], c["va"], use_saved=True)
     gp, gf, gp3, gf3 = (t.cpu().numpy() for t in (gp, gf, gp3, gf3))
     assert np.all(np.isfinite(gp)) and np.all(np.isfinite(gf))
-    assert np.max(np.abs(gp3 - gp)) < 1e-11 * np.max(np.abs(gp))
-    assert np.max(np.abs(gf3 - gf)) < 1e-11 * np.max(np.abs(gf))
+    # (round 3: both kernels take the point's rotation from one function with pinned roundings, so the projection is the same bits
+    #  whoever samples it: the parameter gradient agrees exactly, the table adjoint to the order of its LDS atomics -- 4e-16 measured;
+    #  with cos(atan(y / x)) in one kernel and x / |xi_e| in the other the bound had to be 1e-11)
+    assert np.max(np.abs(gp3 - gp)) <= 1e-14 * np.max(np.abs(gp)), np.max(np.abs(gp3 - gp)) / np.max(np.abs(gp))
+    assert np.max(np.abs(gf3 - gf)) < 1e-13 * np.max(np.abs(gf)), np.max(np.abs(gf3 - gf)) / np.max(np.abs(gf))
 
     def J(f):
         return float((eng.form_factor_2d(0, X, f, c["ud"], c["va"]) * Pbar).sum())

@@ -93,4 +93,6 @@ constexpr int kFusedMaxIon = 2;  // k_spectrum_fused is instantiated for n_ion <
 
 }  // namespace tsff
 
+#ifndef TSFF_NO_API   // (scratch translation units that instantiate single kernels for a look at their assembly: scripts/isa_one.sh)
 #include "tsff_api.inc"
+#endif
