@@ -193,24 +193,35 @@ def config4_main(args):
                                ("configs[3]: arts-2d angular, non-Maxwellian f_e on a 256x256 v-grid, 512 scattering angles x 1024 lambda, "
                                 "one plasma condition (parity unpinned against the reference; pinned to the oracle)"),
                    "nv": nv, "n_angles": na, "n_lambda": npts, "points": npts * na, "bicubic_samples": samples},
-        # configs[3] (table through L1/L2): the sampler keeps the 4 x 4 stencil in a rolling register window and REQUESTS only the entering
-        # row and column -- 64 B per sample; the roofline counts the bytes the kernel loads, not the 128 B of stencil a sample consumes
-        "roofline": {"bound": "lds" if arts else "l1", "achieved": req_bytes / kavg_s / 1e12, "peak": lds_peak if arts else l1_peak, "unit": "TB/s",
-                     "frac": req_bytes / kavg_s / 1e12 / (lds_peak if arts else l1_peak), "traffic": None,
-                     "kernel": "k_form_factor_2d<1,true,4,false> (table in LDS, one ds_read_b64 per stencil entry)" if arts else
-                               "k_form_factor_2d<1,false,1,false> (table read through L1/L2 from the padded copy of k_pad2d and its transpose; rolling 4x4 window)",
-                     "kernel_avg_ms": kavg_s * 1e3, "kernel_median_ms": float(np.median(kt)),
-                     "algorithmic_bytes_per_launch": req_bytes,
-                     "note": ("achieved = 128 B of stencil read from LDS per bicubic sample x samples / kernel time; peak = 256 B per clock and CU of "
-                              "ds_read_b64 x 256 CUs x 2.4 GHz (conflict-free; the sampler's rotated lines measure 2.0 passes per read); the kernel is "
-                              "VALU-issue bound first (fp64_valu)") if arts else
-                             ("achieved = the 64 B per bicubic sample the rolling window REQUESTS (entering row + column of the 4 x 4 stencil) x samples / "
-                              "kernel time; peak = vector-L1 read rate measured on this device by tsff_l1_read_peak (16-byte loads from a 16 KB window); "
-                              "HBM traffic is the 532 KB table + 4 MB of P.  The binding resource is VALU issue, see fp64_valu / "
-                              "profiles/*_2d_sq_counters.json"),
-                     "fp64_valu": {"achieved_tflops": flop / kavg_s / 1e12, "peak": FP64_PEAK / 1e12, "frac": flop / kavg_s / FP64_PEAK,
-                                   "flop_per_sample": 60.0}},
     }
+    valu_per_sample = 75.0 if arts else 93.0   # static count of the sampling loop (scripts/isa_mix.py on the kernel: profiles/r02d / r03 notes in DESIGN.md 4.3)
+    issue = samples / 64.0 * valu_per_sample * 4.0 / (1024 * 2.4e9 * kavg_s)
+    fp64 = {"bound": "fp64-valu", "achieved": flop / kavg_s / 1e12, "peak": FP64_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop / kavg_s / FP64_PEAK,
+            "flop_per_sample": 60.0, "issue_slot_frac": issue, "valu_instructions_per_sample": valu_per_sample,
+            "kernel_avg_ms": kavg_s * 1e3, "kernel_median_ms": float(np.median(kt)), "traffic": None,
+            "note": "frac: 60 flop per bicubic sample (two Catmull-Rom weight sets + the 16-term contraction) / kernel time / 78.6 TF; "
+                    "issue_slot_frac: the sampling loop's VALU instructions per sample (static count) x samples / 64 lanes x 4 cycles / (1024 SIMDs x "
+                    "2.4 GHz x kernel time) -- what the kernel is bound by; HBM traffic is the table + 4 MB of P"}
+    if arts:
+        res["roofline"] = {"bound": "lds", "achieved": req_bytes / kavg_s / 1e12, "peak": lds_peak, "unit": "TB/s", "frac": req_bytes / kavg_s / 1e12 / lds_peak,
+                           "traffic": None, "kernel": "k_form_factor_2d<1,true,4,false> (table in LDS, one ds_read_b64 per stencil entry)",
+                           "kernel_avg_ms": kavg_s * 1e3, "kernel_median_ms": float(np.median(kt)), "algorithmic_bytes_per_launch": req_bytes,
+                           "note": "achieved = 128 B of stencil read from LDS per bicubic sample x samples / kernel time; peak = 256 B per clock and CU of "
+                                   "ds_read_b64 x 256 CUs x 2.4 GHz (conflict-free; the sampler's rotated lines measure 2.0 passes per read); the kernel is "
+                                   "VALU-issue bound first (roofline_fp64)"}
+        res["roofline_fp64"] = fp64
+    else:
+        # configs[3] (table through L1/L2): FP64-VALU issue is the stated bound (with no requests at all the loop takes 90.6 ms: the floor);
+        # the L1 view counts what the rolling window may REQUEST -- the entering row and column, 64 B per sample, each only in the lanes
+        # whose cell moves on that axis -- never the 128 B of stencil a sample consumes
+        fp64["kernel"] = ("k_form_factor_2d<1,false,1,false> (table read through L1/L2 from the padded copy of k_pad2d and its transpose; rolling 4x4 "
+                          "window, requests one sample ahead)")
+        res["roofline"] = fp64
+        res["roofline_l1"] = {"bound": "l1", "achieved_upper": req_bytes / kavg_s / 1e12, "peak": l1_peak, "unit": "TB/s",
+                              "frac_upper": req_bytes / kavg_s / 1e12 / l1_peak,
+                              "note": "upper bound of the requested bytes (64 B per sample if every lane's cell moved on both axes every sample; the "
+                                      "requests are masked to the lanes that shift: ~0.9 of the lanes on the major axis, ~0.37 on the minor one) / "
+                                      "kernel time against the vector-L1 read rate tsff_l1_read_peak measures on this device"}
     if cpu_res is not None:
         res["cpu_baseline"] = cpu_res
     print(json.dumps(res))
