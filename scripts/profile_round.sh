@@ -28,3 +28,4 @@ python3 bench.py --forward-only --batch 256 --steps 50 --warmup 5 > profiles/${t
 bash scripts/pmc.sh ${tag} > gpurun_out/${tag}_sq.txt 2>&1
 bash scripts/pmc.sh ${tag}_twosweep "k_spectrum<1, 1, 0" --plan 2 >> gpurun_out/${tag}_sq.txt 2>&1
 tail -30 gpurun_out/${tag}_sq.txt
+bash scripts/pmc_cfg4.sh ${tag} > gpurun_out/${tag}_cfg4_sq.txt 2>&1; cp gpurun_out/${tag}_cfg4_counters.json profiles/ 2>/dev/null; tail -12 gpurun_out/${tag}_cfg4_sq.txt

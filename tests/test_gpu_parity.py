@@ -1247,6 +1247,11 @@ def test_full_batch_against_cpp_oracle(torch_mod, B):
     for s in act:  # per column: relative to the column's largest entry, every lineout
         assert np.max(np.abs(g[:, s] - gref[:, s])) < 1e-6 * np.max(np.abs(gref[:, s])), s
     assert np.all(g[:, gm == 0] == 0.0)
+    # tsff_forward on the same batch (BASELINE configs[1] is B = 256 forward-only): the pair-sweep forward kernel in its 512-thread
+    # one-round form (B = 37, 256) and with three workgroups per CU (B = 4096) -- the bits of the loss kernel's spectra, hence the
+    # oracle's to the same 1e-8 / 1e-7, every lineout
+    Ef, If = eng.forward(X, batch["e_amps"], batch["i_amps"], noise_e=batch.get("noise_e"), noise_i=batch.get("noise_i"))
+    assert bool((Ef == E).all()) and bool((If == I).all())
 
 
 def test_forward_pass_like_calc_series(torch_mod):
