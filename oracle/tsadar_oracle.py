@@ -678,7 +678,7 @@ def calc_chi_vals_2d(vx, DF, beta, xie_mag, klde_mag):
     return fe_vphi, chiEI, chiERrat
 
 
-def form_factor_2d(lam_range, npts, lam_shift, sa_deg, num_grad_points, p, vx, fe2d, ud_angle, va_angle, lam_index=None):
+def form_factor_2d(lam_range, npts, lam_shift, sa_deg, num_grad_points, p, vx, fe2d, ud_angle, va_angle, lam_index=None, debug=None):
     """``FormFactor.calc_in_2D`` (form_factor.py:449-587), one lineout.  Returns (P[G, npts, ntheta], lam_cm).
     ``lam_index`` restricts the evaluation to a subset of the wavelength samples (the 2-D path has no coupling
     along lambda), which keeps this O(npts * ntheta * nv^2) restatement affordable in tests."""
@@ -725,6 +725,8 @@ def form_factor_2d(lam_range, npts, lam_shift, sa_deg, num_grad_points, p, vx, f
     xie = ((a * kx - ud[0]) / vTe, (a * ky - ud[1]) / vTe)
     xie_mag = np.sqrt(xie[0] ** 2 + xie[1] ** 2)
     beta = np.arctan(xie[1] / xie[0]) + np.pi * (-np.heaviside(xie[0], 1) + 1)
+    if debug is not None:   # (tests: which rotation angles a deck exercises)
+        debug["beta"] = beta
     shp = beta.shape
     fe_vphi = np.empty(shp)
     chiEI = np.empty(shp)

@@ -728,6 +728,35 @@ def test_form_factor_2d_matches_oracle(torch_mod, kind, nv):
             assert err < 1e-7, (feature, b, err)
 
 
+def test_rolling_sampler_every_walk_direction(torch_mod):
+    """The sampler for tables read through L1/L2 (nv = 132 > 128: project_rolling) is compiled in eight forms -- direction of the cell
+    walk on each axis x orientation of the table copy it reads -- chosen per point from the rotation angle beta.  Away from the laser line
+    beta is the direction of +-k (second / fourth quadrant for every scattering angle); within ~0.02 nm of it the drift term of xi_e wins,
+    so drift directions in all four quadrants and samples of the ION window around the line make the points of this test cover all eight
+    forms (asserted from the oracle's own beta); every point against the oracle's restatement of calc_in_2D, 1e-7."""
+    cfg = decks.deck_fit()
+    nv = 132
+    sa = dict(sa=np.array([25.0, 40.0, 62.0, 88.0, 115.0, 150.0]), weights=np.ones((1, 6)) / 6)
+    eng = _engine(cfg, sa)
+    normed = util.random_lineouts(cfg, 1, seed=67, ranges=dict(ud=(-1.5, 1.5)))
+    phys = orc.physical_params(cfg["parameters"], normed, True)
+    vx, fe2 = _fe2d(nv, "anisotropic")
+    idx = np.array([3, 226, 231, 234, 235, 236, 239, 244, 1020])   # (the laser line, 526.094 nm, lies at sample 234.7 of the ion window)
+    seen = set()
+    for ud, ud_ang, va_ang in ((1.4, 25.0, -40.0), (1.4, 115.0, 200.0), (-1.2, 60.0, 10.0), (0.9, 290.0, 135.0)):
+        phys["ud"] = np.array([ud])
+        X = util.normed_to_matrix(phys, 1)
+        P = eng.form_factor_2d(1, X, fe2, ud_ang, va_ang).cpu().numpy()
+        dbg = {}
+        Po, _ = orc.form_factor_2d(cfg["other"]["lamrangI"], 1024, 0.0, sa["sa"], 1, orc.lineout_params(phys, 0, 1), vx, fe2, ud_ang, va_ang,
+                                   lam_index=idx, debug=dbg)
+        err = np.max(np.abs(P[0][:, idx, :] - Po) / np.abs(Po))
+        assert err < 1e-7, (ud, ud_ang, va_ang, err)
+        cb, sb = np.cos(dbg["beta"]).ravel(), np.sin(dbg["beta"]).ravel()
+        seen |= set(zip((cb >= 0).tolist(), (sb >= 0).tolist(), (np.abs(sb) > np.abs(cb)).tolist()))
+    assert len(seen) == 8, sorted(seen)
+
+
 def _angular_sa(cfg):
     """tests/test_forward/test_angular_1v.py:53-60: the geometry is looked up as spectype "angular", then the deck is
     switched to "angular_full"."""
