@@ -152,6 +152,13 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  tsadar_amd has no CPU fallback."
         )
+    # torch first: libtsff.so needs libamdhip64, and the HIP runtime of the process must be the one torch brings (device memory, streams
+    # and events are shared with it).  Loaded before torch, the library binds /opt/rocm's copy, torch then loads its own, and
+    # tsff_create finds "no HIP device" (seen with build() and smoke() in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
