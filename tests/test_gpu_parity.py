@@ -702,13 +702,13 @@ def _fe2d(nv, kind):
     return vx, f / (f.sum() * (vx[1] - vx[0]) ** 2)
 
 
-@pytest.mark.parametrize("kind,nv", [("maxwellian", 48), ("anisotropic", 48), ("anisotropic", 132)])
+@pytest.mark.parametrize("kind,nv", [("maxwellian", 48), ("anisotropic", 48), ("anisotropic", 132), ("anisotropic", 133)])
 def test_form_factor_2d_matches_oracle(torch_mod, kind, nv):
     """a16: FormFactor.calc_in_2D (rotate + project + ratintn per (lambda, theta) point) vs the oracle's
     restatement on a subset of wavelengths; non-zero drift and flow at oblique angles.  (Parity with the reference
     itself is unpinned for this path: its goldens are not in the reference tree.)"""
     cfg = decks.deck_fit()
-    B = 2  # nv = 48: table resident in LDS; nv = 132 (> 128): table read through L1/L2
+    B = 2  # nv = 48: table resident in LDS; nv = 132 (> 128): table read through L1/L2; 133: an odd number of samples per line (the sampler's loop is unrolled by two)
     sa = dict(sa=np.array([35.0, 60.0, 110.0]), weights=np.ones((B, 3)) / 3)
     eng = _engine(cfg, sa)
     normed = util.random_lineouts(cfg, B, seed=61, ranges=dict(ud=(-1.5, 1.5)))
