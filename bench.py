@@ -518,7 +518,7 @@ def main():
             "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % (os.path.basename(tfile) if tfile else "-"),
             "algorithmic_bytes_per_launch": B * abytes,
             "kernel": (("k_forward_pairs<1,*,2,1> (512 threads per item: one dispatch round)" if 2 * B <= 512 else
-                        "k_fused_prep + k_forward_pairs<1,*,1,2> (256 threads per item)") if args.forward_only else
+                        "k_fused_prep + k_forward_pairs<1,*,*,2> (256 threads per item, three workgroups per CU when the LDS allows)") if args.forward_only else
                        ("k_spectrum<1,1,2,256,false> (two-sweep kernel with table adjoints)" if args.free_form else
                         ("k_fused_prep + k_spectrum_fused<1,%d,*> (2B 256-thread workgroups, one sweep over the points); k_fused_finish behind it" % (1 if args.dlm else 0)
                          if args.ppp == 1 else
