@@ -1431,6 +1431,15 @@ def test_rows_kernel_points_per_pixel(torch_mod, ppp, n_ion, active):
             np.testing.assert_array_equal(out[0][k], again[k])
     for k in (2, 3):
         np.testing.assert_array_equal(out[0][k], out[2][k])
+    # tsff_forward at several points per pixel: the forward form of the rounds kernel (k_spectrum_rows<..., FWD>) in its small-batch
+    # form (plan 0: one workgroup per round), as one workgroup for all rounds (plan 1) and k_spectrum MODE 0 (plan 2) -- the bits of the
+    # loss kernels' spectra, every time
+    for plan in (0, 0, 1, 2):
+        eng.set_launch_plan(plan)
+        Ef, If = eng.forward(X, batch["e_amps"], batch["i_amps"], noise_e=batch["noise_e"], noise_i=batch["noise_i"], fe=None)
+        np.testing.assert_array_equal(Ef.cpu().numpy(), out[0][2])
+        np.testing.assert_array_equal(If.cpu().numpy(), out[0][3])
+    eng.set_launch_plan(0)
     # (the loss sums are folded over 256 threads x 4 bins here, over 512 x 2 by the two-sweep kernel's one-feature workgroups)
     np.testing.assert_allclose(out[0][0], out[2][0], rtol=1e-14)
     np.testing.assert_allclose(out[0][1], out[2][1], rtol=1e-10, atol=1e-12 * np.abs(out[0][1]).max())   # (sums of 10^4 terms in another order)
