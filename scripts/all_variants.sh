@@ -12,3 +12,7 @@ run --dlm
 run --free-form
 run --nvx 320
 run --nvx 320 --dlm
+run --forward-only --ppp 5 --batch 1024
+run --forward-only --ppp 2
+run --forward-only --ppp 5 --batch 16
+run --ppp 5 --batch 16
