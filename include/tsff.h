@@ -164,7 +164,7 @@ int tsff_set_stream(tsff_handle *h, void *hip_stream);
  * through a scratch array in device memory that the handle allocates on first use: B x loaded features x (8 + 3 n_ion) x npts
  * doubles, 1 GB at B = 1024 and 5 points per pixel (above 16 GB the two-sweep kernel is used instead).  Bit 0: never interleave (both features in one 512-thread workgroup) and never spread the
  * rounds of a lineout over several workgroups (the small-batch form of the several-points-per-pixel kernel); bit 1: always the
- * two-sweep kernel; bit 2: never three forward-only workgroups per CU (tsff_forward runs three 256-thread workgroups per CU when
+ * two-sweep kernel (and, for tsff_forward at several points per pixel, k_spectrum instead of the forward form of the rounds kernel); bit 2: never three forward-only workgroups per CU (tsff_forward runs three 256-thread workgroups per CU when
  * the batch is large enough to need them); bit 3: the one-sweep kernel evaluates every base point itself instead of taking its pair's
  * right neighbour from the next lane; bit 5 (32): the per-lineout W tables by the 128 x 128-tiled GEMM instead of the 128 x 144 one (bit 4 is
  * unused and refused).  The spectra are identical either way; the gradient differs by rounding.
